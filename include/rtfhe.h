@@ -1,0 +1,130 @@
+/*
+ * rtfhe.h -- C ABI of librtfhe_hip.so, the MI355X (gfx950) engine for the HomNAND hot path of
+ * hideki1217/rusTfhe.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo root):
+ *
+ *   rtfhe_ctx_create / _destroy      <- thread_local FFT_MAP + Spqlios_new / Spqlios_destructor
+ *                                       (utils/src/math.rs:349-360, utils/src/spqlios.rs:18-20,139-145)
+ *   rtfhe_load_bk_torus              <- BootstrappingKey::new's TRGSWRepF::from (hom_nand/src/tfhe.rs:119-126,
+ *                                       hom_nand/src/trgsw.rs:68-76)
+ *   rtfhe_load_bk_fft                <- BootstrappingKey(Vec<TRGSWRepF>) as the reference holds it (tfhe.rs:116)
+ *   rtfhe_load_ksk                   <- KeySwitchingKey(Vec<[[TLWERep;3];8]>) (hom_nand/src/tlwe.rs:243-245)
+ *   rtfhe_gate_batch[_dev]           <- TFHE::hom_nand/and/or/xor/not (hom_nand/src/tfhe.rs:41-71), count gates at once
+ *   rtfhe_mux_batch                  <- TFHE::hom_mux (tfhe.rs:27-40)
+ *   rtfhe_bootstrap_batch            <- TFHE::bootstrap (tfhe.rs:73-80)
+ *   rtfhe_blind_rotate_batch         <- TFHE::blind_rotate with the gate test vector (tfhe.rs:81-113)
+ *   rtfhe_external_product_batch     <- Cross for TRGSWRepF (hom_nand/src/trgsw.rs:264-306)
+ *   rtfhe_key_switch_batch           <- TLWERep::identity_key_switch (hom_nand/src/tlwe.rs:43-73)
+ *   rtfhe_ifft_i32_batch             <- Spqlios_ifft_i32 / _u32 (utils/src/spqlios.rs:22-23, spqlios-wrapper.cpp:22-28)
+ *   rtfhe_fft_u32_batch              <- Spqlios_fft_u32 (utils/src/spqlios.rs:25, spqlios-wrapper.cpp:34-36)
+ *   rtfhe_keygen / rtfhe_tlwe_*      <- TFHE::new, Cryptor::encrypto/decrypto(TLWE, ..) (tfhe.rs:21-25, tlwe.rs:213-241)
+ *
+ * Conventions: every call returns 0 on success or a negative rtfhe_status; nothing aborts or throws
+ * across the ABI; rtfhe_last_error() gives the message of the last failure on that context.  The caller
+ * owns every buffer.  Host-pointer calls copy in/out and are synchronous; *_dev calls take device
+ * pointers, enqueue on the given hipStream_t (passed as void*) and return without synchronising.
+ * A context is bound to one device and is not thread-safe (the reference's handle is not either:
+ * one per thread, utils/src/math.rs:349-351).  There is NO CPU fallback: without a usable HIP device
+ * rtfhe_ctx_create fails with RTFHE_ERR_NO_DEVICE.
+ *
+ * Flat little-endian layouts (the reference defines none):
+ *   TLWE lvl0   u32[n+1]           a[0..n), b
+ *   TLWE lvl1   u32[N+1]           a'[0..N), b'
+ *   TRLWE       u32[2][N]          b(X), a(X)
+ *   BK torus    u32[n][2][2l][N]   comp 0 = TRGSWRep.cipher rows, comp 1 = TRGSWRep.p_key rows
+ *   BK fft      f64[n][2][2l][N]   same order; each poly an FrrSeries: Re[0..N/2) then Im[0..N/2),
+ *                                  in the transform's native order (utils/src/spqlios.rs:147,205-208)
+ *   KSK         u32[N][t][base-1][n+1]
+ */
+#ifndef RTFHE_H
+#define RTFHE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtfhe_ctx rtfhe_ctx;
+
+typedef struct {
+    int32_t n;          /* TLWE lvl0 dimension    (635)   hom_nand/src/tlwe.rs:175  */
+    int32_t N;          /* TRLWE degree           (1024)  hom_nand/src/trlwe.rs:76  */
+    int32_t nbit;       /* log2(N)                (10)    hom_nand/src/tfhe.rs:16   */
+    int32_t l;          /* gadget levels          (3)     hom_nand/src/trgsw.rs:115 */
+    int32_t bgbit;      /* gadget base bits       (6)     hom_nand/src/trgsw.rs:112 */
+    int32_t ks_t;       /* key-switch levels      (8)     hom_nand/src/tlwe.rs:178  */
+    int32_t ks_basebit; /* key-switch base bits   (2)     hom_nand/src/tlwe.rs:179  */
+} rtfhe_params;
+
+typedef enum {
+    RTFHE_NAND = 0, RTFHE_AND = 1, RTFHE_OR = 2, RTFHE_XOR = 3, RTFHE_NOT = 4, RTFHE_COPY = 5
+} rtfhe_gate;
+
+typedef enum {
+    RTFHE_OK = 0,
+    RTFHE_ERR_INVALID = -1,     /* bad argument / unsupported parameter set */
+    RTFHE_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    RTFHE_ERR_HIP = -3,         /* a HIP runtime call failed */
+    RTFHE_ERR_STATE = -4,       /* keys not loaded yet */
+    RTFHE_ERR_NOMEM = -5
+} rtfhe_status;
+
+/* ---- context ---- */
+void rtfhe_default_params(rtfhe_params *p);
+int rtfhe_ctx_create(const rtfhe_params *p, int device_id, rtfhe_ctx **out);
+void rtfhe_ctx_destroy(rtfhe_ctx *ctx);
+const char *rtfhe_last_error(const rtfhe_ctx *ctx);   /* ctx may be NULL: last ctx-less error */
+const char *rtfhe_version(void);
+int rtfhe_device_count(void);
+/* twiddle tables in the reference's memory layout (2N doubles each direction; blocks 4 cos | 4 sin) */
+int rtfhe_get_twiddles(const rtfhe_ctx *ctx, double *ifft_table, double *fft_table);
+int rtfhe_set_twiddles(rtfhe_ctx *ctx, const double *ifft_table, const double *fft_table);
+
+/* ---- keys ---- */
+int rtfhe_load_bk_torus(rtfhe_ctx *ctx, const uint32_t *bk /* [n][2][2l][N] */);
+int rtfhe_load_bk_fft(rtfhe_ctx *ctx, const double *bk_f /* [n][2][2l][N] */);
+int rtfhe_export_bk_fft(rtfhe_ctx *ctx, double *bk_f /* [n][2][2l][N] */);
+int rtfhe_load_ksk(rtfhe_ctx *ctx, const uint32_t *ksk /* [N][t][base-1][n+1] */);
+
+/* ---- the hot path: host buffers ---- */
+int rtfhe_gate_batch(rtfhe_ctx *ctx, int op, const uint32_t *in0, const uint32_t *in1,
+                     uint32_t *out, size_t count);            /* [count][n+1] each; in1 ignored for NOT/COPY */
+int rtfhe_mux_batch(rtfhe_ctx *ctx, const uint32_t *c, const uint32_t *in0, const uint32_t *in1,
+                    uint32_t *out, size_t count);
+int rtfhe_bootstrap_batch(rtfhe_ctx *ctx, const uint32_t *tlwe, uint32_t *out, size_t count);
+
+/* ---- the hot path: device buffers, asynchronous on `stream` (a hipStream_t, may be NULL) ---- */
+int rtfhe_gate_batch_dev(rtfhe_ctx *ctx, int op, const void *d_in0, const void *d_in1, void *d_out,
+                         size_t count, void *stream);
+int rtfhe_sync(rtfhe_ctx *ctx, void *stream);
+/* device-side timing of the launches enqueued by the *_dev calls between begin and end (HIP events on
+ * `stream`); end returns total milliseconds and the number of kernel launches */
+int rtfhe_timer_begin(rtfhe_ctx *ctx, void *stream);
+int rtfhe_timer_end(rtfhe_ctx *ctx, void *stream, double *ms, int64_t *launches);
+
+/* ---- stage-level entry points (parity tests; same kernels' building blocks) ---- */
+int rtfhe_blind_rotate_batch(rtfhe_ctx *ctx, const uint32_t *tlwe /* [count][n+1] */, int32_t steps,
+                             uint32_t *acc /* [count][2][N] */, size_t count);
+int rtfhe_external_product_batch(rtfhe_ctx *ctx, const int32_t *bk_index /* [count] */,
+                                 const uint32_t *trlwe /* [count][2][N] */, uint32_t *out, size_t count);
+int rtfhe_key_switch_batch(rtfhe_ctx *ctx, const uint32_t *tlwe1 /* [count][N+1] */,
+                           uint32_t *out /* [count][n+1] */, size_t count);
+int rtfhe_ifft_i32_batch(rtfhe_ctx *ctx, const int32_t *src /* [count][N] */, double *res /* [count][N] */, size_t count);
+int rtfhe_fft_u32_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, uint32_t *res /* [count][N] */, size_t count);
+
+/* ---- key generation / encryption (host side; own seeded generator, the reference's is thread_rng) ---- */
+int rtfhe_keygen(const rtfhe_params *p, uint64_t seed, int32_t *key0 /* [n] */, int32_t *key1 /* [N] */,
+                 uint32_t *bk /* [n][2][2l][N] */, uint32_t *ksk /* [N][t][base-1][n+1] */);
+int rtfhe_tlwe_encrypt_bits(const rtfhe_params *p, const int32_t *key0, uint64_t seed,
+                            const uint8_t *bits, uint32_t *out /* [count][n+1] */, size_t count);
+int rtfhe_tlwe_decrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint32_t *in,
+                            uint8_t *bits, size_t count);
+int rtfhe_tlwe_phase(const rtfhe_params *p, const int32_t *key0, const uint32_t *in, uint32_t *phase, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

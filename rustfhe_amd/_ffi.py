@@ -1,0 +1,91 @@
+"""ctypes binding of librtfhe_hip.so (the C ABI declared in include/rtfhe.h).
+
+There is no fallback: if the shared library is missing it is built with hipcc; if that is impossible
+an ImportError/RuntimeError is raised.  Nothing here ever touches oracle/.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Params(C.Structure):
+    """rtfhe_params; defaults = the reference's constants (tlwe.rs:175-180, trlwe.rs:76, trgsw.rs:112-115, tfhe.rs:16)."""
+    _fields_ = [(k, C.c_int32) for k in ("n", "N", "nbit", "l", "bgbit", "ks_t", "ks_basebit")]
+
+    def __init__(self, n=635, N=1024, nbit=None, l=3, bgbit=6, ks_t=8, ks_basebit=2):
+        super().__init__()
+        self.n, self.N, self.l, self.bgbit, self.ks_t, self.ks_basebit = n, N, l, bgbit, ks_t, ks_basebit
+        self.nbit = nbit if nbit is not None else int(N).bit_length() - 1
+
+    @property
+    def bk_words(self):
+        return self.n * 2 * 2 * self.l * self.N
+
+    @property
+    def ksk_words(self):
+        return self.N * self.ks_t * ((1 << self.ks_basebit) - 1) * (self.n + 1)
+
+
+NAND, AND, OR, XOR, NOT, COPY = range(6)
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+
+_SIGNATURES = {
+    "rtfhe_default_params": (None, ["PP"]),
+    "rtfhe_ctx_create": (C.c_int, ["PP", C.c_int, C.POINTER(C.c_void_p)]),
+    "rtfhe_ctx_destroy": (None, [C.c_void_p]),
+    "rtfhe_last_error": (C.c_char_p, [C.c_void_p]),
+    "rtfhe_version": (C.c_char_p, []),
+    "rtfhe_device_count": (C.c_int, []),
+    "rtfhe_get_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_set_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_load_bk_torus": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_load_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_export_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_load_ksk": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_gate_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_mux_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_gate_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rtfhe_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_timer_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "rtfhe_blind_rotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "rtfhe_external_product_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_key_switch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_ifft_i32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_u32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_keygen": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_tlwe_decrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_tlwe_phase": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Loads (building first if needed) librtfhe_hip.so.  Raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        _build.build()
+    if not os.path.exists(_build.LIB):
+        raise ImportError("librtfhe_hip.so is missing and could not be built (hipcc required); "
+                          "rustfhe_amd has no CPU fallback")
+    L = C.CDLL(_build.LIB)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)   # AttributeError here = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = [C.POINTER(Params) if a == "PP" else a for a in args]
+    _lib = L
+    return L

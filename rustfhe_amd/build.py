@@ -1,0 +1,39 @@
+"""Builds rustfhe_amd/librtfhe_hip.so in-tree with hipcc for gfx950.
+
+-ffp-contract=off is REQUIRED for parity: the reference's AVX FFT rounds every product and sum
+separately (no FMA); hipcc fuses to v_fma_f64 by default.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librtfhe_hip.so")
+SOURCES = ["rtfhe_api.hip", "rtfhe_keygen.cpp"]
+DEPS = SOURCES + ["rtfhe_device.hpp", "rtfhe_kernels.hpp", os.path.join("..", "..", "include", "rtfhe.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not (force or stale()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])

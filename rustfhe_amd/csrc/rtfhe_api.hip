@@ -1,0 +1,577 @@
+// rtfhe_api.hip -- C ABI (include/rtfhe.h) over the gfx950 kernels.  No CPU fallback: every compute
+// entry point runs HIP kernels or fails with an error code.
+#include "../../include/rtfhe.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtfhe_kernels.hpp"
+
+using namespace rtfhe;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// ------------------------------------------------------------------------------------------------
+// twiddle tables (host).  Values follow the reference's table builders so that a context created in
+// the same process / against the same libm as the reference holds the same bits:
+//   accurate_cos / accurate_sin   utils/src/spqlios/spqlios-fft-impl.cpp:99-113
+//   new_ifft_table                utils/src/spqlios/spqlios-fft-impl.cpp:400-437
+//   new_fft_table                 utils/src/spqlios/spqlios-fft-impl.cpp:158-193
+// ------------------------------------------------------------------------------------------------
+double quad_cos(int i, int n) {
+    i = ((i % n) + n) % n;
+    if (i >= 3 * n / 4) return std::cos(2. * M_PI * (n - i) / double(n));
+    if (i >= 2 * n / 4) return -std::cos(2. * M_PI * (i - n / 2) / double(n));
+    if (i >= 1 * n / 4) return -std::cos(2. * M_PI * (n / 2 - i) / double(n));
+    return std::cos(2. * M_PI * (i) / double(n));
+}
+double quad_sin(int i, int n) {
+    i = ((i % n) + n) % n;
+    if (i >= 3 * n / 4) return -std::sin(2. * M_PI * (n - i) / double(n));
+    if (i >= 2 * n / 4) return -std::sin(2. * M_PI * (i - n / 2) / double(n));
+    if (i >= 1 * n / 4) return std::sin(2. * M_PI * (n / 2 - i) / double(n));
+    return std::sin(2. * M_PI * (i) / double(n));
+}
+
+struct HostTw {
+    int N = 0;
+    // per-stage natural order; forward stages concatenated halfnn = P/2 .. 4, inverse halfnn = 4 .. P/2
+    std::vector<double> twist_c, twist_s, untw_c, untw_s, fwd_c, fwd_s, inv_c, inv_s;
+    int fwd_off(int halfnn) const { return N / 2 - 2 * halfnn; }
+    int inv_off(int halfnn) const { return halfnn - 4; }
+
+    void build(int N_) {
+        N = N_;
+        const int n = 2 * N, P = N / 2;
+        twist_c.assign(P, 0); twist_s.assign(P, 0); untw_c.assign(P, 0); untw_s.assign(P, 0);
+        fwd_c.assign(P, 0); fwd_s.assign(P, 0); inv_c.assign(P, 0); inv_s.assign(P, 0);
+        for (int j = 0; j < P; j++) {
+            twist_c[j] = quad_cos(j, n);  twist_s[j] = quad_sin(j, n);
+            untw_c[j] = quad_cos(-j, n);  untw_s[j] = quad_sin(-j, n);
+        }
+        for (int halfnn = P / 2; halfnn >= 4; halfnn /= 2) {
+            const int j = n / (2 * halfnn);
+            for (int k = 0; k < halfnn; k++) {
+                fwd_c[fwd_off(halfnn) + k] = quad_cos(j * k, n);
+                fwd_s[fwd_off(halfnn) + k] = quad_sin(j * k, n);
+                inv_c[inv_off(halfnn) + k] = quad_cos(-j * k, n);
+                inv_s[inv_off(halfnn) + k] = quad_sin(-j * k, n);
+            }
+        }
+    }
+    // reference memory layout: per stage, blocks | c0 c1 c2 c3 | s0 s1 s2 s3 |
+    static size_t put(double* dst, const double* c, const double* s, int cnt) {
+        size_t w = 0;
+        for (int i = 0; i < cnt; i += 4) {
+            for (int k = 0; k < 4; k++) dst[w++] = c[i + k];
+            for (int k = 0; k < 4; k++) dst[w++] = s[i + k];
+        }
+        return w;
+    }
+    static size_t get(const double* src, double* c, double* s, int cnt) {
+        size_t r = 0;
+        for (int i = 0; i < cnt; i += 4) {
+            for (int k = 0; k < 4; k++) c[i + k] = src[r++];
+            for (int k = 0; k < 4; k++) s[i + k] = src[r++];
+        }
+        return r;
+    }
+    void export_ref(double* ifft_table, double* fft_table) const {
+        const int P = N / 2;
+        std::memset(ifft_table, 0, sizeof(double) * 2 * N);
+        std::memset(fft_table, 0, sizeof(double) * 2 * N);
+        size_t w = put(ifft_table, twist_c.data(), twist_s.data(), P);
+        for (int h = P / 2; h >= 4; h /= 2) w += put(ifft_table + w, fwd_c.data() + fwd_off(h), fwd_s.data() + fwd_off(h), h);
+        w = 0;
+        for (int h = 4; h <= P / 2; h *= 2) w += put(fft_table + w, inv_c.data() + inv_off(h), inv_s.data() + inv_off(h), h);
+        put(fft_table + w, untw_c.data(), untw_s.data(), P);
+    }
+    void import_ref(const double* ifft_table, const double* fft_table) {
+        const int P = N / 2;
+        size_t r = get(ifft_table, twist_c.data(), twist_s.data(), P);
+        for (int h = P / 2; h >= 4; h /= 2) r += get(ifft_table + r, fwd_c.data() + fwd_off(h), fwd_s.data() + fwd_off(h), h);
+        r = 0;
+        for (int h = 4; h <= P / 2; h *= 2) r += get(fft_table + r, inv_c.data() + inv_off(h), inv_s.data() + inv_off(h), h);
+        get(fft_table + r, untw_c.data(), untw_s.data(), P);
+    }
+
+    // device table: per direction [twist R*64][pass1 (R-1)*64][pass2 (R-1)*NLOW][pass3 NLOW-4]
+    template <int LOGN>
+    std::vector<cplx> device_table() const {
+        typedef Geo<LOGN> G;
+        std::vector<cplx> t(G::TW_TOTAL);
+        for (int dir = 0; dir < 2; dir++) {
+            cplx* d = t.data() + dir * G::TW_DIR;
+            const double* tc = dir ? untw_c.data() : twist_c.data();
+            const double* ts = dir ? untw_s.data() : twist_s.data();
+            const double* sc = dir ? inv_c.data() : fwd_c.data();
+            const double* ss = dir ? inv_s.data() : fwd_s.data();
+            auto off = [&](int halfnn) { return dir ? inv_off(halfnn) : fwd_off(halfnn); };
+            for (int m = 0; m < G::R; m++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int pos = G::pos1(lane, m);
+                    d[G::TW_TWIST + m * 64 + lane] = make_double2(tc[pos], ts[pos]);
+                }
+            for (int mb = G::LR - 1; mb >= 0; mb--) {
+                const int h = 1 << mb;
+                for (int q = 0; q < h; q++) {
+                    const int e = G::R - 2 * h + q;
+                    for (int lane = 0; lane < 64; lane++) {           // pass 1: global halfnn = 64 h
+                        const int idx = lane + 64 * q;
+                        d[G::TW_P1 + e * 64 + lane] = make_double2(sc[off(64 * h) + idx], ss[off(64 * h) + idx]);
+                    }
+                    for (int r = 0; r < G::NLOW; r++) {               // pass 2: global halfnn = NLOW h
+                        const int idx = (q << G::LOW) | r;
+                        d[G::TW_P2 + e * G::NLOW + r] = make_double2(sc[off(G::NLOW * h) + idx], ss[off(G::NLOW * h) + idx]);
+                    }
+                }
+            }
+            for (int mb = G::LOW - 1; mb >= 2; mb--) {                // pass 3: global halfnn = h, wave-uniform
+                const int h = 1 << mb;
+                for (int q = 0; q < h; q++)
+                    d[G::TW_P3 + G::NLOW - 2 * h + q] = make_double2(sc[off(h) + q], ss[off(h) + q]);
+            }
+        }
+        return t;
+    }
+};
+
+}  // namespace
+
+struct rtfhe_ctx {
+    rtfhe_params p{};
+    int device = 0;
+    int logn = 10;
+    HostTw tw;
+    cplx* d_tw = nullptr;
+    cplx* d_bk = nullptr;
+    uint32_t* d_ksk = nullptr;
+    int ksw = 0;
+    bool has_bk = false, has_ksk = false;
+    void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr;   // staging for host-pointer calls
+    size_t cap_a = 0, cap_b = 0, cap_c = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t launches = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(rtfhe_ctx* ctx, int code, const std::string& msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHECK(ctx, expr)                                                                         \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return fail(ctx, RTFHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+int waves_for(int logn) { return logn == 10 ? 4 : 2; }
+constexpr int KSQ = 3;   // uint4 loads per lane per key-switch row: rows up to 768 words
+
+size_t bk_cplx_count(const rtfhe_params& p) { return (size_t)p.n * 2 * 2 * p.l * (p.N / 2); }
+size_t bk_word_count(const rtfhe_params& p) { return (size_t)p.n * 2 * 2 * p.l * p.N; }
+size_t ksk_rows(const rtfhe_params& p) { return (size_t)p.N * p.ks_t * ((1 << p.ks_basebit) - 1); }
+
+int ensure(rtfhe_ctx* ctx, void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *ptr) return 0;
+    if (*ptr) HIPCHECK(ctx, hipFree(*ptr));
+    *ptr = nullptr; *cap = 0;
+    HIPCHECK(ctx, hipMalloc(ptr, bytes ? bytes : 16));
+    *cap = bytes;
+    return 0;
+}
+
+template <typename K>
+int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
+    HIPCHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <int LOGN>
+int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    constexpr int W = (LOGN == 10) ? 4 : 2;
+    auto k = k_bootstrap<LOGN, 3, 6, 8, 2, KSQ, W>;
+    const size_t lds = bootstrap_lds_bytes<LOGN>(W, a.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    const int grid = (a.count + W - 1) / W;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
+int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
+                     size_t count, hipStream_t s) {
+    if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
+    if (mode == MODE_GATE && !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "key-switching key not loaded");
+    if (count == 0) return 0;
+    if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
+    BootstrapArgs a{};
+    a.tw = ctx->d_tw; a.bk = ctx->d_bk; a.ksk = ctx->d_ksk;
+    a.in0 = (const uint32_t*)d_in0; a.in1 = (const uint32_t*)(d_in1 ? d_in1 : d_in0); a.out = (uint32_t*)d_out;
+    a.count = (int)count; a.op = op; a.n = ctx->p.n; a.steps = steps; a.mode = mode; a.ksw = ctx->ksw;
+    a.npad = (ctx->p.n + 1 + 63) / 64 * 64;
+    return ctx->logn == 10 ? launch_bootstrap_t<10>(ctx, a, s) : launch_bootstrap_t<11>(ctx, a, s);
+}
+
+template <int LOGN>
+int launch_fft_t(rtfhe_ctx* ctx, bool forward, FftArgs a, hipStream_t s) {
+    constexpr int W = 4;
+    typedef Geo<LOGN> G;
+    const size_t lds = (size_t)(G::TW_DIR + W * G::XSLOTS) * sizeof(cplx);
+    int grid = (a.count + W - 1) / W;
+    if (grid > 2048) grid = 2048;
+    if (forward) {
+        auto k = k_fft_forward<LOGN, W>;
+        if (int rc = allow_lds(ctx, k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, s, a);
+    } else {
+        auto k = k_fft_inverse<LOGN, W>;
+        if (int rc = allow_lds(ctx, k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, s, a);
+    }
+    HIPCHECK(ctx, hipGetLastError());
+    return 0;
+}
+int launch_fft(rtfhe_ctx* ctx, bool forward, FftArgs a, hipStream_t s) {
+    if (a.count == 0) return 0;
+    return ctx->logn == 10 ? launch_fft_t<10>(ctx, forward, a, s) : launch_fft_t<11>(ctx, forward, a, s);
+}
+
+template <int LOGN>
+int launch_extprod_t(rtfhe_ctx* ctx, ExtProdArgs a, hipStream_t s) {
+    constexpr int W = (LOGN == 10) ? 4 : 2;
+    auto k = k_external_product<LOGN, 3, 6, W>;
+    const size_t lds = bootstrap_lds_bytes<LOGN>(W, 0);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3((a.count + W - 1) / W), dim3(64 * W), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+template <int LOGN>
+int launch_keyswitch_t(rtfhe_ctx* ctx, KeySwitchArgs a, hipStream_t s) {
+    constexpr int W = 4;
+    auto k = k_key_switch<LOGN, 8, 2, KSQ, W>;
+    const size_t lds = (size_t)W * (1 << LOGN) * 4;
+    hipLaunchKernelGGL(k, dim3((a.count + W - 1) / W), dim3(64 * W), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+template <int LOGN>
+int launch_permute_t(rtfhe_ctx* ctx, const double* src, double* dst, size_t count, int dir, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_bk_permute<LOGN>, dim3(2048), dim3(256), 0, s, src, dst, count, dir, rows);
+    HIPCHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int upload_twiddles(rtfhe_ctx* ctx) {
+    std::vector<cplx> t = ctx->logn == 10 ? ctx->tw.device_table<10>() : ctx->tw.device_table<11>();
+    if (!ctx->d_tw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tw, t.size() * sizeof(cplx)));
+    HIPCHECK(ctx, hipMemcpy(ctx->d_tw, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int use(rtfhe_ctx* ctx) {
+    if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rtfhe_default_params(rtfhe_params* p) {
+    p->n = 635; p->N = 1024; p->nbit = 10; p->l = 3; p->bgbit = 6; p->ks_t = 8; p->ks_basebit = 2;
+}
+
+const char* rtfhe_version(void) { return "rtfhe-hip 0.1 (gfx950, fft64-mirror)"; }
+
+const char* rtfhe_last_error(const rtfhe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int rtfhe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
+    if (!p || !out) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (p->N != 1024 && p->N != 2048) return fail(nullptr, RTFHE_ERR_INVALID, "supported TRLWE degrees: N = 1024, 2048");
+    if (p->nbit != ilog2(p->N)) return fail(nullptr, RTFHE_ERR_INVALID, "nbit must be log2(N)");
+    if (p->l != 3 || p->bgbit != 6) return fail(nullptr, RTFHE_ERR_INVALID, "supported gadget: l = 3, bgbit = 6");
+    if (p->ks_t != 8 || p->ks_basebit != 2) return fail(nullptr, RTFHE_ERR_INVALID, "supported key switch: t = 8, basebit = 2");
+    if (p->n < 1 || p->n + 1 > 256 * KSQ) return fail(nullptr, RTFHE_ERR_INVALID, "supported TLWE dimension: 1 <= n <= 767");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RTFHE_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, RTFHE_ERR_INVALID, "device_id out of range");
+    rtfhe_ctx* ctx = new (std::nothrow) rtfhe_ctx();
+    if (!ctx) return fail(nullptr, RTFHE_ERR_NOMEM, "out of host memory");
+    ctx->p = *p; ctx->device = device_id; ctx->logn = p->nbit;
+    ctx->ksw = (p->n + 1 + 3) / 4 * 4;
+    ctx->tw.build(p->N);
+    int rc = use(ctx);
+    if (!rc) rc = upload_twiddles(ctx);
+    if (!rc && hipStreamCreate(&ctx->stream) != hipSuccess) rc = fail(ctx, RTFHE_ERR_HIP, "hipStreamCreate failed");
+    if (!rc && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess))
+        rc = fail(ctx, RTFHE_ERR_HIP, "hipEventCreate failed");
+    if (rc) { g_last_error = ctx->err; rtfhe_ctx_destroy(ctx); return rc; }
+    *out = ctx;
+    return 0;
+}
+
+void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+    if (ctx->d_bk) (void)hipFree(ctx->d_bk);
+    if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
+    if (ctx->d_a) (void)hipFree(ctx->d_a);
+    if (ctx->d_b) (void)hipFree(ctx->d_b);
+    if (ctx->d_c) (void)hipFree(ctx->d_c);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rtfhe_get_twiddles(const rtfhe_ctx* ctx, double* ifft_table, double* fft_table) {
+    if (!ctx || !ifft_table || !fft_table) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
+    ctx->tw.export_ref(ifft_table, fft_table);
+    return 0;
+}
+
+int rtfhe_set_twiddles(rtfhe_ctx* ctx, const double* ifft_table, const double* fft_table) {
+    if (int rc = use(ctx)) return rc;
+    if (!ifft_table || !fft_table) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    ctx->tw.import_ref(ifft_table, fft_table);
+    HIPCHECK(ctx, hipDeviceSynchronize());
+    return upload_twiddles(ctx);
+}
+
+int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
+    if (int rc = use(ctx)) return rc;
+    if (!bk) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    const size_t words = bk_word_count(ctx->p);
+    if (!ctx->d_bk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx)));
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, words * 4)) return rc;
+    HIPCHECK(ctx, hipMemcpy(ctx->d_a, bk, words * 4, hipMemcpyHostToDevice));
+    // TRGSWRepF::from (trgsw.rs:68-76): ifft_torus = forward transform of the words viewed as signed i32
+    FftArgs a{ctx->d_tw, ctx->d_a, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l};
+    if (int rc = launch_fft(ctx, true, a, ctx->stream)) return rc;
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_bk = true;
+    return 0;
+}
+
+int rtfhe_load_bk_fft(rtfhe_ctx* ctx, const double* bk_f) {
+    if (int rc = use(ctx)) return rc;
+    if (!bk_f) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    const size_t words = bk_word_count(ctx->p);
+    if (!ctx->d_bk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx)));
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, words * 8)) return rc;
+    HIPCHECK(ctx, hipMemcpy(ctx->d_a, bk_f, words * 8, hipMemcpyHostToDevice));
+    const size_t polys = words / ctx->p.N;
+    int rc = ctx->logn == 10 ? launch_permute_t<10>(ctx, (const double*)ctx->d_a, (double*)ctx->d_bk, polys, 0, 2 * ctx->p.l, ctx->stream)
+                             : launch_permute_t<11>(ctx, (const double*)ctx->d_a, (double*)ctx->d_bk, polys, 0, 2 * ctx->p.l, ctx->stream);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_bk = true;
+    return 0;
+}
+
+int rtfhe_export_bk_fft(rtfhe_ctx* ctx, double* bk_f) {
+    if (int rc = use(ctx)) return rc;
+    if (!bk_f) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
+    const size_t words = bk_word_count(ctx->p);
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, words * 8)) return rc;
+    const size_t polys = words / ctx->p.N;
+    int rc = ctx->logn == 10 ? launch_permute_t<10>(ctx, (const double*)ctx->d_bk, (double*)ctx->d_a, polys, 1, 2 * ctx->p.l, ctx->stream)
+                             : launch_permute_t<11>(ctx, (const double*)ctx->d_bk, (double*)ctx->d_a, polys, 1, 2 * ctx->p.l, ctx->stream);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHECK(ctx, hipMemcpy(bk_f, ctx->d_a, words * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
+    if (int rc = use(ctx)) return rc;
+    if (!ksk) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    const size_t rows = ksk_rows(ctx->p), w = (size_t)ctx->p.n + 1, ksw = (size_t)ctx->ksw;
+    // device layout: rows padded to a multiple of 4 words (16-byte loads) + one all-zero row that digit 0 selects
+    std::vector<uint32_t> padded((rows + 1) * ksw, 0u);
+    for (size_t r = 0; r < rows; r++) std::memcpy(padded.data() + r * ksw, ksk + r * w, w * 4);
+    if (!ctx->d_ksk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ksk, padded.size() * 4));
+    HIPCHECK(ctx, hipMemcpy(ctx->d_ksk, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+    ctx->has_ksk = true;
+    return 0;
+}
+
+int rtfhe_gate_batch_dev(rtfhe_ctx* ctx, int op, const void* d_in0, const void* d_in1, void* d_out, size_t count, void* stream) {
+    if (int rc = use(ctx)) return rc;
+    if (op < RTFHE_NAND || op > RTFHE_COPY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
+    if (!d_in0 || !d_out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    return launch_bootstrap(ctx, op, MODE_GATE, ctx->p.n, d_in0, d_in1, d_out, count, (hipStream_t)stream);
+}
+
+int rtfhe_sync(rtfhe_ctx* ctx, void* stream) {
+    if (int rc = use(ctx)) return rc;
+    HIPCHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int rtfhe_timer_begin(rtfhe_ctx* ctx, void* stream) {
+    if (int rc = use(ctx)) return rc;
+    ctx->launches = 0;
+    HIPCHECK(ctx, hipEventRecord(ctx->ev0, (hipStream_t)stream));
+    return 0;
+}
+
+int rtfhe_timer_end(rtfhe_ctx* ctx, void* stream, double* ms, int64_t* launches) {
+    if (int rc = use(ctx)) return rc;
+    HIPCHECK(ctx, hipEventRecord(ctx->ev1, (hipStream_t)stream));
+    HIPCHECK(ctx, hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    HIPCHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    if (ms) *ms = (double)f;
+    if (launches) *launches = ctx->launches;
+    return 0;
+}
+
+static int run_host_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const uint32_t* in0, const uint32_t* in1,
+                              uint32_t* out, size_t count, size_t out_words) {
+    if (int rc = use(ctx)) return rc;
+    if (!in0 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    const size_t in_bytes = count * ((size_t)ctx->p.n + 1) * 4, out_bytes = count * out_words * 4;
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, out_bytes)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, in0, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const void* d1 = nullptr;
+    if (in1) {
+        if (int rc = ensure(ctx, &ctx->d_b, &ctx->cap_b, in_bytes)) return rc;
+        HIPCHECK(ctx, hipMemcpyAsync(ctx->d_b, in1, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d1 = ctx->d_b;
+    }
+    if (int rc = launch_bootstrap(ctx, op, mode, steps, ctx->d_a, d1, ctx->d_c, count, ctx->stream)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(out, ctx->d_c, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rtfhe_gate_batch(rtfhe_ctx* ctx, int op, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
+    if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
+    if (op < RTFHE_NAND || op > RTFHE_COPY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
+    const bool unary = (op == RTFHE_NOT || op == RTFHE_COPY);
+    if (!unary && !in1) return fail(ctx, RTFHE_ERR_INVALID, "binary gate needs two inputs");
+    return run_host_bootstrap(ctx, op, MODE_GATE, ctx->p.n, in0, unary ? nullptr : in1, out, count, (size_t)ctx->p.n + 1);
+}
+
+int rtfhe_bootstrap_batch(rtfhe_ctx* ctx, const uint32_t* tlwe, uint32_t* out, size_t count) {
+    return rtfhe_gate_batch(ctx, RTFHE_COPY, tlwe, nullptr, out, count);
+}
+
+int rtfhe_blind_rotate_batch(rtfhe_ctx* ctx, const uint32_t* tlwe, int32_t steps, uint32_t* acc, size_t count) {
+    if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
+    if (steps < 0 || steps > ctx->p.n) return fail(ctx, RTFHE_ERR_INVALID, "steps out of range");
+    return run_host_bootstrap(ctx, RTFHE_COPY, MODE_BLIND_ROTATE, steps, tlwe, nullptr, acc, count, (size_t)2 * ctx->p.N);
+}
+
+// hom_mux (tfhe.rs:27-40): AND(c, in1), AND(-c, in0), then bootstrap(i1 + i0 + 1/8)
+int rtfhe_mux_batch(rtfhe_ctx* ctx, const uint32_t* c, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
+    if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
+    if (!c || !in0 || !in1 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    const size_t w = (size_t)ctx->p.n + 1, total = count * w;
+    std::vector<uint32_t> nc(total), i1(total), i0(total);
+    if (int rc = rtfhe_gate_batch(ctx, RTFHE_AND, c, in1, i1.data(), count)) return rc;
+    for (size_t k = 0; k < total; k++) nc[k] = 0u - c[k];
+    if (int rc = rtfhe_gate_batch(ctx, RTFHE_AND, nc.data(), in0, i0.data(), count)) return rc;
+    for (size_t g = 0; g < count; g++) {
+        for (size_t k = 0; k < w; k++) nc[g * w + k] = i1[g * w + k] + i0[g * w + k];
+        nc[g * w + w - 1] += 0x20000000u;
+    }
+    return rtfhe_bootstrap_batch(ctx, nc.data(), out, count);
+}
+
+int rtfhe_external_product_batch(rtfhe_ctx* ctx, const int32_t* bk_index, const uint32_t* trlwe, uint32_t* out, size_t count) {
+    if (int rc = use(ctx)) return rc;
+    if (!bk_index || !trlwe || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
+    if (count == 0) return 0;
+    for (size_t g = 0; g < count; g++)
+        if (bk_index[g] < 0 || bk_index[g] >= ctx->p.n) return fail(ctx, RTFHE_ERR_INVALID, "bk_index out of range");
+    const size_t bytes = count * 2 * (size_t)ctx->p.N * 4;
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_b, &ctx->cap_b, count * 4)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, bytes)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, trlwe, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_b, bk_index, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    ExtProdArgs a{ctx->d_tw, ctx->d_bk, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count};
+    int rc = ctx->logn == 10 ? launch_extprod_t<10>(ctx, a, ctx->stream) : launch_extprod_t<11>(ctx, a, ctx->stream);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(out, ctx->d_c, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rtfhe_key_switch_batch(rtfhe_ctx* ctx, const uint32_t* tlwe1, uint32_t* out, size_t count) {
+    if (int rc = use(ctx)) return rc;
+    if (!tlwe1 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (!ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "key-switching key not loaded");
+    if (count == 0) return 0;
+    const size_t in_bytes = count * ((size_t)ctx->p.N + 1) * 4, out_bytes = count * ((size_t)ctx->p.n + 1) * 4;
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, out_bytes)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, tlwe1, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    KeySwitchArgs a{ctx->d_ksk, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count, ctx->p.n, ctx->ksw};
+    int rc = ctx->logn == 10 ? launch_keyswitch_t<10>(ctx, a, ctx->stream) : launch_keyswitch_t<11>(ctx, a, ctx->stream);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(out, ctx->d_c, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int run_fft_batch(rtfhe_ctx* ctx, bool forward, const void* src, void* res, size_t count) {
+    if (int rc = use(ctx)) return rc;
+    if (!src || !res) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    const size_t N = (size_t)ctx->p.N;
+    const size_t in_bytes = count * N * (forward ? 4 : 8), out_bytes = count * N * (forward ? 8 : 4);
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, out_bytes)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    FftArgs a{ctx->d_tw, ctx->d_a, ctx->d_c, (int32_t)count, 0, 0};
+    if (int rc = launch_fft(ctx, forward, a, ctx->stream)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(res, ctx->d_c, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rtfhe_ifft_i32_batch(rtfhe_ctx* ctx, const int32_t* src, double* res, size_t count) {
+    return run_fft_batch(ctx, true, src, res, count);
+}
+
+int rtfhe_fft_u32_batch(rtfhe_ctx* ctx, const double* src, uint32_t* res, size_t count) {
+    return run_fft_batch(ctx, false, src, res, count);
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// rtfhe_device.hpp -- gfx950 device building blocks for the HomNAND hot path.
+//
+// One 64-lane wavefront owns one polynomial transform (and, in the bootstrap kernel, one whole
+// gate): the N/2-point complex FP64 transform is held R = N/128 points per lane and runs as three
+// in-register radix-R passes separated by two wave-private LDS exchanges.  No workgroup barrier is
+// ever needed inside a transform.
+//
+// Parity: the arithmetic DAG (which two values meet in which butterfly, which twiddle multiplies
+// which difference, every product and sum rounded on its own -- the file is compiled with
+// -ffp-contract=off) is exactly the one of the reference's native FFT:
+//   forward  = `ifft`  spqlios-ifft-avx.s:64-272  (readable spec ifft_model, spqlios-fft-impl.cpp:469-641)
+//   inverse  = `fft`   spqlios-fft-avx.s:79-280   (readable spec fft_model,  spqlios-fft-impl.cpp:204-397)
+// Only the schedule differs (which lane/register holds which point, and when).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtfhe {
+
+typedef double2 cplx;  // .x = re / cos, .y = im / sin
+
+__host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+// Geometry of the N/2-point transform on one wavefront.
+//   layout L1: lane t,           register m <-> point  t + 64 m                    (m = top LR bits)
+//   layout L2: lane (B,r),       register m <-> point (B << 6) | (m << LOW) | r    (m = middle LR bits)
+//   layout L3: lane v,           register m <-> point (v << LR) | m                (m = low LR bits)
+template <int LOGN>
+struct Geo {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int P = N / 2;
+    static constexpr int LOGP = LOGN - 1;
+    static constexpr int R = P / 64;
+    static constexpr int LR = ilog2(R);
+    static constexpr int LOW = LOGP - 2 * LR;
+    static constexpr int NLOW = 1 << LOW;
+    static_assert(LOW >= 2 && LOW <= LR, "supported: N = 1024, 2048");
+    // twiddle table (cplx units), one per direction
+    static constexpr int TW_TWIST = 0;                         // [R][64]
+    static constexpr int TW_P1 = TW_TWIST + R * 64;            // [R-1][64]
+    static constexpr int TW_P2 = TW_P1 + (R - 1) * 64;         // [R-1][NLOW]
+    static constexpr int TW_P3 = TW_P2 + (R - 1) * NLOW;       // [NLOW-4]  (stages with halfnn >= 4 left for pass 3)
+    static constexpr int TW_DIR = TW_P3 + (NLOW - 4);          // cplx per direction
+    static constexpr int TW_TOTAL = 2 * TW_DIR;                // forward then inverse
+    // LDS exchange buffer, cplx slots
+    static constexpr int XSLOTS = P + 64;
+    __host__ __device__ static constexpr int f1(int pos) { return pos + NLOW * (pos >> 6); }   // L1 <-> L2
+    __host__ __device__ static constexpr int f2(int pos) { return pos + (pos >> LR); }         // L2 <-> L3
+    __host__ __device__ static constexpr int pos1(int lane, int m) { return lane + 64 * m; }
+    __host__ __device__ static constexpr int pos2(int lane, int m) {
+        return ((lane >> LOW) << 6) | (m << LOW) | (lane & (NLOW - 1));
+    }
+    __host__ __device__ static constexpr int pos3(int lane, int m) { return (lane << LR) | m; }
+};
+
+// A wave-private LDS hand-off: DS instructions of one wave execute in order, so no s_barrier is
+// needed; this only stops the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------
+// butterflies (one register-index bit MB at a time; h = 1 << MB; q = m & (h-1) selects the twiddle)
+// ---------------------------------------------------------------------------------------------
+
+// DIF, twiddled: x0' = x0 + x1 ; x1' = (x0 - x1) * w      (spqlios-fft-impl.cpp:546-569)
+template <int R, int MB>
+__device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], const cplx* __restrict__ tw, int stride) {
+    constexpr int h = 1 << MB;
+    cplx w[h];
+#pragma unroll
+    for (int q = 0; q < h; q++) w[q] = tw[q * stride];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & h) continue;
+        const int m1 = m | h, q = m & (h - 1);
+        const double sr = re[m] + re[m1], si = im[m] + im[m1];
+        const double dr = re[m] - re[m1], di = im[m] - im[m1];
+        re[m] = sr; im[m] = si;
+        double a = dr * w[q].x, b = di * w[q].y;
+        re[m1] = a - b;
+        a = dr * w[q].y; b = di * w[q].x;
+        im[m1] = a + b;
+    }
+}
+
+// DIT, twiddled: t = x1 * w ; x0' = x0 + t ; x1' = x0 - t   (spqlios-fft-impl.cpp:346-359)
+template <int R, int MB>
+__device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], const cplx* __restrict__ tw, int stride) {
+    constexpr int h = 1 << MB;
+    cplx w[h];
+#pragma unroll
+    for (int q = 0; q < h; q++) w[q] = tw[q * stride];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & h) continue;
+        const int m1 = m | h, q = m & (h - 1);
+        const double t0 = re[m1] * w[q].x, t1 = re[m1] * w[q].y, t2 = im[m1] * w[q].x, t3 = im[m1] * w[q].y;
+        const double tr = t0 - t3, ti = t1 + t2;
+        const double ar = re[m], ai = im[m];
+        re[m] = ar + tr; im[m] = ai + ti;
+        re[m1] = ar - tr; im[m1] = ai - ti;
+    }
+}
+
+// halfnn = 1 (both directions): (x0 + x1, x0 + (-x1))   (spqlios-fft-impl.cpp:248-269, 612-633)
+template <int R>
+__device__ __forceinline__ void stage_size2(double (&re)[R], double (&im)[R]) {
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double r0 = re[m], r1 = re[m + 1], j0 = im[m], j1 = im[m + 1];
+        re[m] = r0 + r1; re[m + 1] = r0 + (-r1);
+        im[m] = j0 + j1; im[m + 1] = j0 + (-j1);
+    }
+}
+
+// forward halfnn = 2: x0+x2, x1+x3, x0-x2, i*(x1-x3)   (spqlios-fft-impl.cpp:581-602)
+template <int R>
+__device__ __forceinline__ void fwd_stage_size4(double (&re)[R], double (&im)[R]) {
+#pragma unroll
+    for (int m = 0; m < R; m += 4) {
+        const double r0 = re[m], r1 = re[m + 1], r2 = re[m + 2], r3 = re[m + 3];
+        const double j0 = im[m], j1 = im[m + 1], j2 = im[m + 2], j3 = im[m + 3];
+        re[m] = r0 + r2; re[m + 1] = r1 + r3; re[m + 2] = r0 + (-r2); re[m + 3] = (-j1) + j3;
+        im[m] = j0 + j2; im[m + 1] = j1 + j3; im[m + 2] = j0 + (-j2); im[m + 3] = r1 + (-r3);
+    }
+}
+
+// inverse halfnn = 2: x0+x2, x1-i*x3, x0-x2, x1+i*x3   (spqlios-fft-impl.cpp:289-310)
+template <int R>
+__device__ __forceinline__ void inv_stage_size4(double (&re)[R], double (&im)[R]) {
+#pragma unroll
+    for (int m = 0; m < R; m += 4) {
+        const double r0 = re[m], r1 = re[m + 1], r2 = re[m + 2], r3 = re[m + 3];
+        const double j0 = im[m], j1 = im[m + 1], j2 = im[m + 2], j3 = im[m + 3];
+        re[m] = r0 + r2; re[m + 1] = r1 + j3;    re[m + 2] = r0 + (-r2); re[m + 3] = r1 + (-j3);
+        im[m] = j0 + j2; im[m + 1] = j1 + (-r3); im[m + 2] = j0 + (-j2); im[m + 3] = j1 + r3;
+    }
+}
+
+// (re,im) * (c,s):  re*c - im*s , im*c + re*s   (spqlios-fft-impl.cpp:512-517, 390-395)
+template <int R>
+__device__ __forceinline__ void twist_mul(double (&re)[R], double (&im)[R], const cplx* __restrict__ tw) {
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const cplx w = tw[m * 64];
+        const double rc = re[m] * w.x, ic = im[m] * w.x, rs = re[m] * w.y, is = im[m] * w.y;
+        re[m] = rc - is;
+        im[m] = ic + rs;
+    }
+}
+
+template <int R, int LR, int MBTOP>
+struct P12 {   // passes 1 and 2: all LR register bits, twiddled
+    __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* tw, int stride) {
+        // stage MB uses entries [R - 2h, R - h) of the pass table
+        if constexpr (MBTOP >= 0) {
+            constexpr int h = 1 << MBTOP;
+            fwd_stage_tw<R, MBTOP>(re, im, tw + (R - 2 * h) * stride, stride);
+            P12<R, LR, MBTOP - 1>::fwd(re, im, tw, stride);
+        }
+    }
+    __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* tw, int stride) {
+        if constexpr (MBTOP >= 0) {
+            constexpr int h = 1 << MBTOP;
+            P12<R, LR, MBTOP - 1>::inv(re, im, tw, stride);
+            inv_stage_tw<R, MBTOP>(re, im, tw + (R - 2 * h) * stride, stride);
+        }
+    }
+};
+
+template <int R, int NLOW, int MBTOP>
+struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uniform twiddles), bits 1, 0 special
+    __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* tw) {
+        if constexpr (MBTOP >= 2) {
+            constexpr int h = 1 << MBTOP;
+            fwd_stage_tw<R, MBTOP>(re, im, tw + (NLOW - 2 * h), 1);
+            P3<R, NLOW, MBTOP - 1>::fwd(re, im, tw);
+        } else {
+            fwd_stage_size4<R>(re, im);
+            stage_size2<R>(re, im);
+        }
+    }
+    __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* tw) {
+        if constexpr (MBTOP >= 2) {
+            constexpr int h = 1 << MBTOP;
+            P3<R, NLOW, MBTOP - 1>::inv(re, im, tw);
+            inv_stage_tw<R, MBTOP>(re, im, tw + (NLOW - 2 * h), 1);
+        } else {
+            stage_size2<R>(re, im);
+            inv_stage_size4<R>(re, im);
+        }
+    }
+};
+
+// Forward transform.  in: layout L1 (re[m], im[m] = point lane + 64 m), not yet twisted.
+// out: layout L3 (point (lane << LR) | m), the FrrSeries "native order" of the reference.
+// tw: LDS, forward table.  xbuf: LDS, wave-private, Geo::XSLOTS slots.
+template <int LOGN>
+__device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
+                                            const cplx* __restrict__ tw, cplx* __restrict__ xbuf, int lane) {
+    typedef Geo<LOGN> G;
+    constexpr int R = G::R;
+    twist_mul<R>(re, im, tw + G::TW_TWIST + lane);
+    P12<R, G::LR, G::LR - 1>::fwd(re, im, tw + G::TW_P1 + lane, 64);
+#pragma unroll
+    for (int m = 0; m < R; m++) xbuf[G::f1(G::pos1(lane, m))] = make_double2(re[m], im[m]);
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f1(G::pos2(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    P12<R, G::LR, G::LR - 1>::fwd(re, im, tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) xbuf[G::f2(G::pos2(lane, m))] = make_double2(re[m], im[m]);
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f2(G::pos3(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    P3<R, G::NLOW, G::LOW - 1>::fwd(re, im, tw + G::TW_P3);
+    wave_lds_sync();
+}
+
+// Inverse transform.  in: layout L3, ALREADY scaled by 2/N.  out: layout L1, untwisted (natural
+// coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
+template <int LOGN>
+__device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
+                                            const cplx* __restrict__ tw, cplx* __restrict__ xbuf, int lane) {
+    typedef Geo<LOGN> G;
+    constexpr int R = G::R;
+    P3<R, G::NLOW, G::LOW - 1>::inv(re, im, tw + G::TW_P3);
+#pragma unroll
+    for (int m = 0; m < R; m++) xbuf[G::f2(G::pos3(lane, m))] = make_double2(re[m], im[m]);
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f2(G::pos2(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    P12<R, G::LR, G::LR - 1>::inv(re, im, tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) xbuf[G::f1(G::pos2(lane, m))] = make_double2(re[m], im[m]);
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f1(G::pos1(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    P12<R, G::LR, G::LR - 1>::inv(re, im, tw + G::TW_P1 + lane, 64);
+    twist_mul<R>(re, im, tw + G::TW_TWIST + lane);
+    wave_lds_sync();
+}
+
+// Torus32(int64_t(x)): truncate toward zero, keep the low 32 bits (fft_processor_spqlios.cpp:182).
+// trunc(x) + 1.5*2^52 is exact for |x| < 2^51 (the path's values stay below 2^50: 2l*N*(Bg/2)*2^31),
+// and the low word of its mantissa is trunc(x) mod 2^32.
+__device__ __forceinline__ uint32_t trunc_to_torus(double x) {
+    const double t = __builtin_trunc(x);
+    const double y = t + 6755399441055744.0;
+    return (uint32_t)__double_as_longlong(y);
+}
+
+// make_decomp_mask(l, bits), utils/src/math.rs:542-560
+__host__ __device__ constexpr uint32_t decomp_mask(int l, int bits) {
+    uint32_t u = 0;
+    if (32 - l * bits != 0) {
+        u += 1u << (32 - l * bits - 1);
+        for (int i = l; i >= 1; i--) u += 1u << (32 - i * bits - 1);
+    } else {
+        for (int i = l - 1; i >= 1; i--) u += 1u << (32 - i * bits - 1);
+    }
+    return u;
+}
+
+// digit j of the pre-masked word u = (x + M) ^ M, sign-extended from `bits` (utils/src/math.rs:314-322)
+__device__ __forceinline__ int32_t decomp_digit(uint32_t u, int bits, int j) {
+    const uint32_t v = (u >> (32 - bits * (j + 1))) & ((1u << bits) - 1u);
+    return (int32_t)((v & (1u << (bits - 1))) * 0xfffffffeu + v);
+}
+
+// negacyclic rotate read: coefficient c of X^r * p, p in LDS (utils/src/math.rs:85-132)
+template <int LOGN>
+__device__ __forceinline__ uint32_t rotated_coef(const uint32_t* __restrict__ p, int c, int r) {
+    constexpr int N = 1 << LOGN;
+    const int e = (c - r) & (2 * N - 1);
+    const uint32_t v = p[e & (N - 1)];
+    return (e >> LOGN) ? (0u - v) : v;
+}
+
+}  // namespace rtfhe

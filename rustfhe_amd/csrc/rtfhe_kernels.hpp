@@ -1,0 +1,404 @@
+// rtfhe_kernels.hpp -- gfx950 kernels of the HomNAND hot path (one wavefront = one gate).
+//
+// Reference functions restated here (paths relative to the reference repo root):
+//   gate pre-step            hom_nand/src/tfhe.rs:27-71
+//   blind rotate             hom_nand/src/tfhe.rs:89-113
+//   CMUX / external product  hom_nand/src/trgsw.rs:264-321, utils/src/spqlios.rs:204-222
+//   gadget decomposition     utils/src/math.rs:300-326 (mask :542-560)
+//   negacyclic rotate        utils/src/math.rs:85-132
+//   sample extract           hom_nand/src/trlwe.rs:110-121
+//   identity key switch      hom_nand/src/tlwe.rs:43-73
+#pragma once
+
+#include "rtfhe_device.hpp"
+
+namespace rtfhe {
+
+enum { OP_NAND = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3, OP_NOT = 4, OP_COPY = 5 };
+enum { MODE_GATE = 0, MODE_BLIND_ROTATE = 1 };
+
+struct BootstrapArgs {
+    const cplx* tw;          // [Geo::TW_TOTAL] forward table then inverse table
+    const cplx* bk;          // device layout [n][2l][2][R][64]
+    const uint32_t* ksk;     // device layout [N*t*(base-1) + 1][ksw]; last row all zero
+    const uint32_t* in0;     // [count][n+1]
+    const uint32_t* in1;     // [count][n+1] (may alias in0)
+    uint32_t* out;           // MODE_GATE: [count][n+1];  MODE_BLIND_ROTATE: [count][2][N]
+    int32_t count;
+    int32_t op;
+    int32_t n;
+    int32_t steps;           // CMUX steps to run (= n for a real gate)
+    int32_t mode;
+    int32_t ksw;             // padded KSK row width in u32 (multiple of 4)
+    int32_t npad;            // per-wave LDS words reserved for the mod-switched mask (>= n+1)
+};
+
+// gate pre-step on one TLWE word (a-part: isb = false, b-part: isb = true), hom_nand/src/tfhe.rs:27-71
+__device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1, bool isb) {
+    const uint32_t c8 = 0x20000000u;   // torus!(1/8), utils/src/math.rs:691-696
+    const uint32_t c4 = 0x40000000u;   // torus!(2 * 1/8)
+    switch (op) {
+        case OP_NAND: return (isb ? c8 : 0u) - (x0 + x1);
+        case OP_AND:  return (x0 + x1) - (isb ? c8 : 0u);
+        case OP_OR:   return (x0 + x1) + (isb ? c8 : 0u);
+        case OP_XOR:  return (x0 + x1) * 2u + (isb ? c4 : 0u);
+        case OP_NOT:  return 0u - x0;
+        default:      return x0;
+    }
+}
+
+// One external product / CMUX on the wave-private accumulator in LDS.
+//   CMUX = true : acc <- cross(bk_i, X^r * acc - acc) + acc      (trgsw.rs:319-321, tfhe.rs:103-110)
+//   CMUX = false: acc <- cross(bk_i, acc)                          (trgsw.rs:264-306)
+// accbuf: LDS u32 [2][N] (b then a).  bk_i: this TRGSW in device layout [2l][2][R][64] cplx.
+template <int LOGN, int L, int BGBIT, bool CMUX>
+__device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, const cplx* __restrict__ bk_i,
+                                          const cplx* __restrict__ twf, const cplx* __restrict__ twi,
+                                          cplx* __restrict__ xbuf, int lane) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, P = G::P, R = G::R;
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+
+    double s0re[R], s0im[R], s1re[R], s1im[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) { s0re[m] = 0.0; s0im[m] = 0.0; s1re[m] = 0.0; s1im[m] = 0.0; }
+
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        const uint32_t* poly = accbuf + h * N;
+        uint32_t u[2 * R];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = lane + 64 * mm;
+            const uint32_t own = poly[c];
+            const uint32_t d = CMUX ? (rotated_coef<LOGN>(poly, c, r) - own) : own;
+            u[mm] = (d + M) ^ M;
+        }
+#pragma unroll 1
+        for (int jj = 0; jj < L; jj++) {
+            const cplx* bkj = bk_i + (size_t)((h * L + jj) * 2) * R * 64 + lane;
+            cplx b0[R], b1[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) { b0[m] = bkj[m * 64]; b1[m] = bkj[(R + m) * 64]; }
+            double re[R], im[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                re[m] = (double)decomp_digit(u[m], BGBIT, jj);
+                im[m] = (double)decomp_digit(u[R + m], BGBIT, jj);
+            }
+            fft_forward<LOGN>(re, im, twf, xbuf, lane);
+            // hadamard + fold-add from zero, utils/src/spqlios.rs:204-222, hom_nand/src/trgsw.rs:290-299
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                {
+                    const double ii = b0[m].y * im[m], rr = b0[m].x * re[m], ri = b0[m].x * im[m], ir = b0[m].y * re[m];
+                    s0re[m] = s0re[m] + (rr - ii);
+                    s0im[m] = s0im[m] + (ir + ri);
+                }
+                {
+                    const double ii = b1[m].y * im[m], rr = b1[m].x * re[m], ri = b1[m].x * im[m], ir = b1[m].y * re[m];
+                    s1re[m] = s1re[m] + (rr - ii);
+                    s1im[m] = s1im[m] + (ir + ri);
+                }
+            }
+        }
+    }
+
+    const double scale = 2.0 / (double)N;   // fft_processor_spqlios.cpp:158
+#pragma unroll 1
+    for (int comp = 0; comp < 2; comp++) {
+        double re[R], im[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            re[m] = (comp ? s1re[m] : s0re[m]) * scale;
+            im[m] = (comp ? s1im[m] : s0im[m]) * scale;
+        }
+        fft_inverse<LOGN>(re, im, twi, xbuf, lane);
+        uint32_t* poly = accbuf + comp * N;
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            const uint32_t x0 = trunc_to_torus(re[m]), x1 = trunc_to_torus(im[m]);
+            if (CMUX) { poly[c] += x0; poly[c + P] += x1; }
+            else      { poly[c] = x0;  poly[c + P] = x1; }
+        }
+    }
+    wave_lds_sync();
+}
+
+// identity key switch of the lvl1 sample held as a'[0..N) in LDS (+ b'), one wave.
+// Rows are subtracted in a different order than the reference's (i, l) loop: wrapping u32 addition is
+// commutative and associative, so the result is bit-identical (hom_nand/src/tlwe.rs:64-72).
+template <int LOGN, int KS_T, int KS_BB, int KSQ>
+__device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ aprime, uint32_t bprime,
+                                                const uint32_t* __restrict__ ksk, int ksw, int n,
+                                                uint32_t* __restrict__ out, int lane) {
+    constexpr int N = 1 << LOGN;
+    constexpr int BASE1 = (1 << KS_BB) - 1;
+    constexpr uint32_t ROUND = (32 - KS_T * KS_BB) != 0 ? (1u << (32 - KS_T * KS_BB - 1)) : 0u;
+    const int zero_row = N * KS_T * BASE1;
+    uint4 sum[KSQ];
+    bool act[KSQ];
+#pragma unroll
+    for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); act[q] = 4 * (lane + 64 * q) < ksw; }
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(aprime[i] + ROUND));
+        uint4 v[KS_T][KSQ];
+#pragma unroll
+        for (int l = 0; l < KS_T; l++) {
+            const uint32_t d = (u >> (32 - KS_BB * (l + 1))) & ((1u << KS_BB) - 1u);
+            const int row = d ? ((i * KS_T + l) * BASE1 + (int)d - 1) : zero_row;
+            const uint4* p = reinterpret_cast<const uint4*>(ksk + (size_t)row * ksw);
+#pragma unroll
+            for (int q = 0; q < KSQ; q++) v[l][q] = act[q] ? p[lane + 64 * q] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int l = 0; l < KS_T; l++)
+#pragma unroll
+            for (int q = 0; q < KSQ; q++) {
+                sum[q].x += v[l][q].x; sum[q].y += v[l][q].y; sum[q].z += v[l][q].z; sum[q].w += v[l][q].w;
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < KSQ; q++) {
+        const int col = 4 * (lane + 64 * q);
+        const uint32_t s[4] = {sum[q].x, sum[q].y, sum[q].z, sum[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (col + e <= n) out[col + e] = ((col + e == n) ? bprime : 0u) - s[e];
+    }
+}
+
+template <int LOGN>
+__host__ __device__ constexpr size_t bootstrap_wave_lds_bytes(int npad) {
+    return (size_t)Geo<LOGN>::XSLOTS * sizeof(cplx) + (size_t)2 * Geo<LOGN>::N * 4 + (size_t)npad * 4;
+}
+template <int LOGN>
+__host__ __device__ constexpr size_t bootstrap_lds_bytes(int waves, int npad) {
+    return (size_t)Geo<LOGN>::TW_TOTAL * sizeof(cplx) + (size_t)waves * bootstrap_wave_lds_bytes<LOGN>(npad);
+}
+
+// The hot-path kernel: pre-step, blind rotate (n CMUX steps), sample extract and identity key switch
+// of `count` independent gates in ONE launch; wave w of block b owns gate b * WAVES + w from start to end.
+template <int LOGN, int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs a) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, R = G::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * WAVES) tw[idx] = a.tw[idx];
+    __syncthreads();
+    // from here on waves never synchronise with each other
+
+    const int g = blockIdx.x * WAVES + wave;
+    if (g >= a.count) return;
+
+    unsigned char* wbase = smem + (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(a.npad);
+    cplx* xbuf = reinterpret_cast<cplx*>(wbase);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(cplx));
+    uint32_t* abar = accbuf + 2 * N;
+    const cplx* twf = tw;
+    const cplx* twi = tw + G::TW_DIR;
+
+    const int n = a.n;
+    // pre-step + mod switch (tfhe.rs:97, 107-108): b floor, a_i rounded, both to [0, 2N)
+    {
+        const uint32_t* p0 = a.in0 + (size_t)g * (n + 1);
+        const uint32_t* p1 = a.in1 + (size_t)g * (n + 1);
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane; i <= n; i += 64) {
+            const uint32_t t = gate_linear(a.op, p0[i], p1[i], i == n);
+            abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
+        }
+    }
+    wave_lds_sync();
+    // acc = X^{-bbar} * testvec, testvec = (1/8, ..., 1/8 ; 0)   (tfhe.rs:85, 98-106)
+    {
+        const int bbar = (int)abar[n];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = lane + 64 * mm;
+            const int e = (c + bbar) & (2 * N - 1);
+            accbuf[c] = (e >> LOGN) ? 0xE0000000u : 0x20000000u;
+            accbuf[N + c] = 0u;
+        }
+    }
+    wave_lds_sync();
+
+    const size_t trgsw_cplx = (size_t)2 * L * 2 * R * 64;
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        cmux_step<LOGN, L, BGBIT, true>(accbuf, r, a.bk + (size_t)i * trgsw_cplx, twf, twi, xbuf, lane);
+    }
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        uint32_t* o = a.out + (size_t)g * 2 * N;
+        for (int c = lane; c < 2 * N; c += 64) o[c] = accbuf[c];
+        return;
+    }
+
+    // sample extract index 0 (trlwe.rs:110-121): a'_0 = a_0, a'_k = -a_{N-k}; b' = b_0
+    uint32_t av[2 * R];
+#pragma unroll
+    for (int mm = 0; mm < 2 * R; mm++) av[mm] = accbuf[N + lane + 64 * mm];
+    const uint32_t bprime = accbuf[0];
+    wave_lds_sync();
+#pragma unroll
+    for (int mm = 0; mm < 2 * R; mm++) {
+        const int c = lane + 64 * mm;
+        accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[mm] : (0u - av[mm]);
+    }
+    wave_lds_sync();
+    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n, a.out + (size_t)g * (n + 1), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level kernels (one wave per item)
+// ------------------------------------------------------------------------------------------------
+
+struct FftArgs {
+    const cplx* tw;
+    const void* src;
+    void* dst;
+    int32_t count;
+    int32_t dst_layout;   // forward: 0 = FrrSeries (Re[0..P) | Im[0..P)), 1 = device BK layout [R][64] cplx
+    int32_t rows;         // dst_layout 1: 2l; source polys ordered [i][comp][row], device polys [i][row][comp]
+};
+
+// source poly index (i, comp, row) -> device poly index (i, row, comp)
+__host__ __device__ inline size_t bk_poly_remap(size_t g, int rows) {
+    const size_t i = g / (2 * (size_t)rows), rem = g % (2 * (size_t)rows);
+    const size_t comp = rem / rows, row = rem % rows;
+    return (i * rows + row) * 2 + comp;
+}
+
+// Spqlios_ifft_i32 / _u32 (spqlios-wrapper.cpp:22-28): count polynomials of N int32 -> FrrSeries
+template <int LOGN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_fft_forward(const FftArgs a) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, P = G::P, R = G::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < G::TW_DIR; idx += 64 * WAVES) tw[idx] = a.tw[idx];
+    __syncthreads();
+    cplx* xbuf = tw + G::TW_DIR + (size_t)wave * G::XSLOTS;
+    for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
+        const int32_t* src = reinterpret_cast<const int32_t*>(a.src) + (size_t)g * N;
+        double re[R], im[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { re[m] = (double)src[lane + 64 * m]; im[m] = (double)src[lane + 64 * m + P]; }
+        fft_forward<LOGN>(re, im, tw, xbuf, lane);
+        if (a.dst_layout == 0) {
+            double* dst = reinterpret_cast<double*>(a.dst) + (size_t)g * N;
+#pragma unroll
+            for (int m = 0; m < R; m++) { dst[G::pos3(lane, m)] = re[m]; dst[P + G::pos3(lane, m)] = im[m]; }
+        } else {
+            cplx* dst = reinterpret_cast<cplx*>(a.dst) + bk_poly_remap((size_t)g, a.rows) * P;
+#pragma unroll
+            for (int m = 0; m < R; m++) dst[m * 64 + lane] = make_double2(re[m], im[m]);
+        }
+    }
+}
+
+// Spqlios_fft_u32 (spqlios-wrapper.cpp:34-36): count FrrSeries -> polynomials of N torus words
+template <int LOGN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_fft_inverse(const FftArgs a) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, P = G::P, R = G::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < G::TW_DIR; idx += 64 * WAVES) tw[idx] = a.tw[G::TW_DIR + idx];
+    __syncthreads();
+    cplx* xbuf = tw + G::TW_DIR + (size_t)wave * G::XSLOTS;
+    const double scale = 2.0 / (double)N;
+    for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
+        const double* src = reinterpret_cast<const double*>(a.src) + (size_t)g * N;
+        double re[R], im[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { re[m] = src[G::pos3(lane, m)] * scale; im[m] = src[P + G::pos3(lane, m)] * scale; }
+        fft_inverse<LOGN>(re, im, tw, xbuf, lane);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(a.dst) + (size_t)g * N;
+#pragma unroll
+        for (int m = 0; m < R; m++) { dst[lane + 64 * m] = trunc_to_torus(re[m]); dst[lane + 64 * m + P] = trunc_to_torus(im[m]); }
+    }
+}
+
+// FrrSeries layout <-> device BK layout, count polynomials (dir 0: FrrSeries -> device, 1: device -> FrrSeries)
+template <int LOGN>
+__global__ void k_bk_permute(const double* __restrict__ src, double* __restrict__ dst, size_t count, int dir, int rows) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, P = G::P;
+    const size_t total = count * P;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = idx / P;
+        const int k = (int)(idx % P);          // device index m * 64 + lane
+        const int m = k >> 6, lane = k & 63;
+        const int pos = G::pos3(lane, m);
+        const size_t gd = bk_poly_remap(g, rows);   // g: FrrSeries-side index, gd: device-side index
+        if (dir == 0) {
+            dst[gd * N + 2 * k] = src[g * N + pos];
+            dst[gd * N + 2 * k + 1] = src[g * N + P + pos];
+        } else {
+            dst[g * N + pos] = src[gd * N + 2 * k];
+            dst[g * N + P + pos] = src[gd * N + 2 * k + 1];
+        }
+    }
+}
+
+struct ExtProdArgs {
+    const cplx* tw;
+    const cplx* bk;
+    const int32_t* bk_index;   // [count]
+    const uint32_t* trlwe;     // [count][2][N]
+    uint32_t* out;             // [count][2][N]
+    int32_t count;
+};
+
+template <int LOGN, int L, int BGBIT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_external_product(const ExtProdArgs a) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, R = G::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * WAVES) tw[idx] = a.tw[idx];
+    __syncthreads();
+    const int g = blockIdx.x * WAVES + wave;
+    if (g >= a.count) return;
+    unsigned char* wbase = smem + (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(0);
+    cplx* xbuf = reinterpret_cast<cplx*>(wbase);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(cplx));
+    for (int c = lane; c < 2 * N; c += 64) accbuf[c] = a.trlwe[(size_t)g * 2 * N + c];
+    wave_lds_sync();
+    const size_t trgsw_cplx = (size_t)2 * L * 2 * R * 64;
+    cmux_step<LOGN, L, BGBIT, false>(accbuf, 0, a.bk + (size_t)a.bk_index[g] * trgsw_cplx, tw, tw + G::TW_DIR, xbuf, lane);
+    for (int c = lane; c < 2 * N; c += 64) a.out[(size_t)g * 2 * N + c] = accbuf[c];
+}
+
+struct KeySwitchArgs {
+    const uint32_t* ksk;
+    const uint32_t* tlwe1;   // [count][N+1]
+    uint32_t* out;           // [count][n+1]
+    int32_t count, n, ksw;
+};
+
+template <int LOGN, int KS_T, int KS_BB, int KSQ, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_key_switch(const KeySwitchArgs a) {
+    constexpr int N = 1 << LOGN;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x * WAVES + wave;
+    if (g >= a.count) return;
+    uint32_t* ap = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * N;
+    const uint32_t* src = a.tlwe1 + (size_t)g * (N + 1);
+    for (int c = lane; c < N; c += 64) ap[c] = src[c];
+    wave_lds_sync();
+    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(ap, src[N], a.ksk, a.ksw, a.n, a.out + (size_t)g * (a.n + 1), lane);
+}
+
+}  // namespace rtfhe

@@ -1,0 +1,165 @@
+// rtfhe_keygen.cpp -- host-side key generation and TLWE encryption/decryption behind the C ABI.
+// Off the timed path (the reference's TFHE::new is setup too, hom_nand/src/tfhe.rs:21-25), kept on the
+// host like the reference's.  Follows:
+//   TLWE encrypt/decrypt       hom_nand/src/tlwe.rs:181-241
+//   TRLWE zero encryption      hom_nand/src/trlwe.rs:127-137
+//   TRGSW encryption of a bit  hom_nand/src/trgsw.rs:118-138,217-229
+//   BootstrappingKey::new      hom_nand/src/tfhe.rs:119-126 (torus form; the device transforms it)
+//   KeySwitchingKey::new       hom_nand/src/tlwe.rs:247-277
+//   torus!(f32)                utils/src/math.rs:691-696
+// The reference draws from rand::thread_rng (unseedable); this uses a seeded xoshiro256** so that key
+// sets are reproducible.  Distributions match (uniform f32-derived torus, Normal f32 noise).
+#include "../../include/rtfhe.h"
+
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Rng {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t& x) {
+        uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    explicit Rng(uint64_t seed) { for (auto& v : s) v = splitmix(seed); }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    float unit() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
+    double unit53() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+uint32_t torus_from_f32(float v) {
+    volatile float w = v - std::floor(v);
+    volatile float fr = w - std::trunc(w);
+    volatile float x = fr * 4294967296.0f;
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)x;
+}
+uint32_t uniform_torus(Rng& r) { return torus_from_f32(r.unit()); }
+uint32_t gaussian_torus(Rng& r, float alpha) {
+    double u1 = r.unit53(), u2 = r.unit53();
+    if (u1 < 1e-300) u1 = 1e-300;
+    const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    return torus_from_f32((float)z * alpha);
+}
+
+void tlwe_encrypt(Rng& r, int n, const int32_t* key, uint32_t msg, float alpha, uint32_t* ct) {
+    uint32_t b = 0;
+    for (int i = 0; i < n; i++) ct[i] = uniform_torus(r);
+    const uint32_t e = gaussian_torus(r, alpha);
+    for (int i = 0; i < n; i++) if (key[i]) b += ct[i];
+    ct[n] = b + e + msg;
+}
+
+// b = a * s + e  (exact negacyclic product with the binary key; the reference uses its FFT here)
+void trlwe_zero(Rng& r, int N, const int32_t* key, float alpha, uint32_t* b, uint32_t* a) {
+    for (int k = 0; k < N; k++) a[k] = uniform_torus(r);
+    for (int k = 0; k < N; k++) b[k] = gaussian_torus(r, alpha);
+    for (int j = 0; j < N; j++) {
+        if (!key[j]) continue;
+        for (int k = 0; k < N - j; k++) b[k + j] += a[k];
+        for (int k = N - j; k < N; k++) b[k + j - N] -= a[k];
+    }
+}
+
+bool valid(const rtfhe_params* p) {
+    return p && p->n > 0 && p->N >= 16 && (p->N & (p->N - 1)) == 0 && p->l > 0 && p->bgbit > 0 && p->l * p->bgbit <= 32 &&
+           p->ks_t > 0 && p->ks_basebit > 0 && p->ks_t * p->ks_basebit <= 32;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtfhe_keygen(const rtfhe_params* p, uint64_t seed, int32_t* key0, int32_t* key1, uint32_t* bk, uint32_t* ksk) {
+    if (!valid(p) || !key0 || !key1) return RTFHE_ERR_INVALID;
+    const int n = p->n, N = p->N, l = p->l, rows = 2 * l;
+    Rng root(seed);
+    for (int i = 0; i < n; i++) key0[i] = (int32_t)(root.next() >> 63);
+    for (int i = 0; i < N; i++) key1[i] = (int32_t)(root.next() >> 63);
+    const float alpha_bk = 1.0f / 33554432.0f;   // 2^-25, trlwe.rs:77
+    const float alpha_ks = 1.0f / 32768.0f;      // 2^-15, tlwe.rs:176
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)(hw ? (hw > 16 ? 16 : hw) : 1);
+    const uint64_t s_bk = root.next(), s_ks = root.next();
+    if (bk) {
+        const size_t trgsw = (size_t)2 * rows * N;
+        auto work = [&](int t) {
+            for (int i = t; i < n; i += nthreads) {
+                Rng r(s_bk + 0x9e3779b97f4a7c15ull * (uint64_t)(i + 1));
+                uint32_t* ct = bk + (size_t)i * trgsw;
+                for (int j = 0; j < rows; j++) trlwe_zero(r, N, key1, alpha_bk, ct + (size_t)j * N, ct + ((size_t)rows + j) * N);
+                const float bg_inv = 1.0f / (float)(1 << p->bgbit);
+                for (int k = 0; k < l; k++) {
+                    float pw = 1.0f;
+                    for (int e = 0; e < 1 + k; e++) pw *= bg_inv;
+                    const uint32_t t2 = torus_from_f32((float)key0[i] * pw);
+                    ct[(size_t)k * N] += t2;
+                    ct[((size_t)rows + k + l) * N] += t2;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    if (ksk) {
+        const int t = p->ks_t, bb = p->ks_basebit, base1 = (1 << bb) - 1;
+        auto work = [&](int tid) {
+            for (int i = tid; i < N; i += nthreads) {
+                Rng r(s_ks + 0xbf58476d1ce4e5b9ull * (uint64_t)(i + 1));
+                for (int lv = 0; lv < t; lv++)
+                    for (int d = 0; d < base1; d++) {
+                        float pw = 1.0f;
+                        for (int e = 0; e < bb * (lv + 1); e++) pw *= 0.5f;
+                        const uint32_t item = torus_from_f32((float)key1[i] * pw * (float)(d + 1));
+                        tlwe_encrypt(r, n, key0, item, alpha_ks, ksk + (((size_t)i * t + lv) * base1 + d) * (size_t)(n + 1));
+                    }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int k = 0; k < nthreads; k++) th.emplace_back(work, k);
+        for (auto& x : th) x.join();
+    }
+    return 0;
+}
+
+int rtfhe_tlwe_encrypt_bits(const rtfhe_params* p, const int32_t* key0, uint64_t seed, const uint8_t* bits, uint32_t* out, size_t count) {
+    if (!valid(p) || !key0 || !bits || !out) return RTFHE_ERR_INVALID;
+    Rng r(seed);
+    for (size_t g = 0; g < count; g++)
+        tlwe_encrypt(r, p->n, key0, torus_from_f32(bits[g] ? 0.125f : -0.125f), 1.0f / 32768.0f, out + g * ((size_t)p->n + 1));
+    return 0;
+}
+
+int rtfhe_tlwe_phase(const rtfhe_params* p, const int32_t* key0, const uint32_t* in, uint32_t* phase, size_t count) {
+    if (!valid(p) || !key0 || !in || !phase) return RTFHE_ERR_INVALID;
+    for (size_t g = 0; g < count; g++) {
+        const uint32_t* ct = in + g * ((size_t)p->n + 1);
+        uint32_t s = 0;
+        for (int i = 0; i < p->n; i++) if (key0[i]) s += ct[i];
+        phase[g] = ct[p->n] - s;
+    }
+    return 0;
+}
+
+int rtfhe_tlwe_decrypt_bits(const rtfhe_params* p, const int32_t* key0, const uint32_t* in, uint8_t* bits, size_t count) {
+    if (!valid(p) || !key0 || !in || !bits) return RTFHE_ERR_INVALID;
+    std::vector<uint32_t> ph(count);
+    if (int rc = rtfhe_tlwe_phase(p, key0, in, ph.data(), count)) return rc;
+    // torus2binary (tlwe.rs:187-194): One iff f32(t) * 2^-32 < 0.5
+    for (size_t g = 0; g < count; g++) bits[g] = ((float)ph[g] * (1.0f / 4294967296.0f) < 0.5f) ? 1 : 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+"""Engine: one rtfhe_ctx (one GPU) behind numpy / torch-device-pointer calls.
+
+Every compute method runs the HIP kernels of librtfhe_hip.so through the C ABI; errors surface as
+RtfheError with the library's message.  No CPU path exists in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import AND, COPY, NAND, NOT, OR, XOR, Params  # noqa: F401
+
+
+class RtfheError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rtfhe error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Engine:
+    def __init__(self, params=None, device=0):
+        self.L = _ffi.load()
+        self.p = params or Params()
+        h = C.c_void_p()
+        rc = self.L.rtfhe_ctx_create(C.byref(self.p), device, C.byref(h))
+        if rc != 0:
+            raise RtfheError(rc, (self.L.rtfhe_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rtfhe_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RtfheError(rc, (self.L.rtfhe_last_error(self.h) or b"").decode())
+
+    # ---- keys -------------------------------------------------------------------------------
+    def load_bk_torus(self, bk):
+        bk = _np(bk, np.uint32).reshape(-1)
+        assert bk.size == self.p.bk_words, "bk must be u32[n][2][2l][N]"
+        self._ck(self.L.rtfhe_load_bk_torus(self.h, _ptr(bk)))
+
+    def load_bk_fft(self, bk_f):
+        bk_f = _np(bk_f, np.float64).reshape(-1)
+        assert bk_f.size == self.p.bk_words, "bk_f must be f64[n][2][2l][N]"
+        self._ck(self.L.rtfhe_load_bk_fft(self.h, _ptr(bk_f)))
+
+    def export_bk_fft(self):
+        out = np.empty(self.p.bk_words, np.float64)
+        self._ck(self.L.rtfhe_export_bk_fft(self.h, _ptr(out)))
+        return out
+
+    def load_ksk(self, ksk):
+        ksk = _np(ksk, np.uint32).reshape(-1)
+        assert ksk.size == self.p.ksk_words, "ksk must be u32[N][t][base-1][n+1]"
+        self._ck(self.L.rtfhe_load_ksk(self.h, _ptr(ksk)))
+
+    def twiddles(self):
+        a = np.zeros(2 * self.p.N, np.float64)
+        b = np.zeros(2 * self.p.N, np.float64)
+        self._ck(self.L.rtfhe_get_twiddles(self.h, _ptr(a), _ptr(b)))
+        return a, b
+
+    def set_twiddles(self, ifft_table, fft_table):
+        a, b = _np(ifft_table, np.float64), _np(fft_table, np.float64)
+        assert a.size == 2 * self.p.N and b.size == 2 * self.p.N
+        self._ck(self.L.rtfhe_set_twiddles(self.h, _ptr(a), _ptr(b)))
+
+    # ---- hot path, host buffers -------------------------------------------------------------
+    def gate_batch(self, op, in0, in1=None):
+        in0 = _np(in0, np.uint32).reshape(-1, self.p.n + 1)
+        if in1 is not None:
+            in1 = _np(in1, np.uint32).reshape(-1, self.p.n + 1)
+            assert in1.shape == in0.shape
+        out = np.empty_like(in0)
+        self._ck(self.L.rtfhe_gate_batch(self.h, op, _ptr(in0), _ptr(in1), _ptr(out), in0.shape[0]))
+        return out
+
+    def mux_batch(self, c, in0, in1):
+        c = _np(c, np.uint32).reshape(-1, self.p.n + 1)
+        in0 = _np(in0, np.uint32).reshape(c.shape)
+        in1 = _np(in1, np.uint32).reshape(c.shape)
+        out = np.empty_like(c)
+        self._ck(self.L.rtfhe_mux_batch(self.h, _ptr(c), _ptr(in0), _ptr(in1), _ptr(out), c.shape[0]))
+        return out
+
+    def bootstrap_batch(self, tlwe):
+        tlwe = _np(tlwe, np.uint32).reshape(-1, self.p.n + 1)
+        out = np.empty_like(tlwe)
+        self._ck(self.L.rtfhe_bootstrap_batch(self.h, _ptr(tlwe), _ptr(out), tlwe.shape[0]))
+        return out
+
+    # ---- hot path, device buffers (torch tensors or raw pointers) ---------------------------
+    @staticmethod
+    def _dev(t):
+        if t is None:
+            return None
+        if isinstance(t, int):
+            return C.c_void_p(t)
+        return C.c_void_p(t.data_ptr())
+
+    def gate_batch_dev(self, op, d_in0, d_in1, d_out, count, stream=None):
+        self._ck(self.L.rtfhe_gate_batch_dev(self.h, op, self._dev(d_in0), self._dev(d_in1), self._dev(d_out),
+                                             count, C.c_void_p(stream) if stream else None))
+
+    def sync(self, stream=None):
+        self._ck(self.L.rtfhe_sync(self.h, C.c_void_p(stream) if stream else None))
+
+    def timer_begin(self, stream=None):
+        self._ck(self.L.rtfhe_timer_begin(self.h, C.c_void_p(stream) if stream else None))
+
+    def timer_end(self, stream=None):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.L.rtfhe_timer_end(self.h, C.c_void_p(stream) if stream else None, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- stage level ------------------------------------------------------------------------
+    def blind_rotate_batch(self, tlwe, steps=None):
+        tlwe = _np(tlwe, np.uint32).reshape(-1, self.p.n + 1)
+        acc = np.empty((tlwe.shape[0], 2, self.p.N), np.uint32)
+        self._ck(self.L.rtfhe_blind_rotate_batch(self.h, _ptr(tlwe), self.p.n if steps is None else steps,
+                                                 _ptr(acc), tlwe.shape[0]))
+        return acc
+
+    def external_product_batch(self, bk_index, trlwe):
+        trlwe = _np(trlwe, np.uint32).reshape(-1, 2, self.p.N)
+        idx = _np(bk_index, np.int32).reshape(-1)
+        assert idx.size == trlwe.shape[0]
+        out = np.empty_like(trlwe)
+        self._ck(self.L.rtfhe_external_product_batch(self.h, _ptr(idx), _ptr(trlwe), _ptr(out), trlwe.shape[0]))
+        return out
+
+    def key_switch_batch(self, tlwe1):
+        tlwe1 = _np(tlwe1, np.uint32).reshape(-1, self.p.N + 1)
+        out = np.empty((tlwe1.shape[0], self.p.n + 1), np.uint32)
+        self._ck(self.L.rtfhe_key_switch_batch(self.h, _ptr(tlwe1), _ptr(out), tlwe1.shape[0]))
+        return out
+
+    def ifft_i32_batch(self, src):
+        src = _np(src, np.int32).reshape(-1, self.p.N)
+        res = np.empty(src.shape, np.float64)
+        self._ck(self.L.rtfhe_ifft_i32_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
+        return res
+
+    def fft_u32_batch(self, src):
+        src = _np(src, np.float64).reshape(-1, self.p.N)
+        res = np.empty(src.shape, np.uint32)
+        self._ck(self.L.rtfhe_fft_u32_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
+        return res
+
+
+# ---- host-side key generation / encryption (C ABI, no GPU needed) --------------------------------
+
+def keygen(params, seed, want_bk=True, want_ksk=True):
+    L = _ffi.load()
+    key0 = np.empty(params.n, np.int32)
+    key1 = np.empty(params.N, np.int32)
+    bk = np.empty(params.bk_words, np.uint32) if want_bk else None
+    ksk = np.empty(params.ksk_words, np.uint32) if want_ksk else None
+    rc = L.rtfhe_keygen(C.byref(params), seed, _ptr(key0), _ptr(key1), _ptr(bk), _ptr(ksk))
+    if rc != 0:
+        raise RtfheError(rc, "rtfhe_keygen failed")
+    return key0, key1, bk, ksk
+
+
+def encrypt_bits(params, key0, bits, seed):
+    L = _ffi.load()
+    bits = _np(bits, np.uint8).reshape(-1)
+    key0 = _np(key0, np.int32)
+    out = np.empty((bits.size, params.n + 1), np.uint32)
+    rc = L.rtfhe_tlwe_encrypt_bits(C.byref(params), _ptr(key0), seed, _ptr(bits), _ptr(out), bits.size)
+    if rc != 0:
+        raise RtfheError(rc, "rtfhe_tlwe_encrypt_bits failed")
+    return out
+
+
+def decrypt_bits(params, key0, cts):
+    L = _ffi.load()
+    cts = _np(cts, np.uint32).reshape(-1, params.n + 1)
+    key0 = _np(key0, np.int32)
+    bits = np.empty(cts.shape[0], np.uint8)
+    rc = L.rtfhe_tlwe_decrypt_bits(C.byref(params), _ptr(key0), _ptr(cts), _ptr(bits), cts.shape[0])
+    if rc != 0:
+        raise RtfheError(rc, "rtfhe_tlwe_decrypt_bits failed")
+    return bits
+
+
+def phases(params, key0, cts):
+    L = _ffi.load()
+    cts = _np(cts, np.uint32).reshape(-1, params.n + 1)
+    key0 = _np(key0, np.int32)
+    ph = np.empty(cts.shape[0], np.uint32)
+    rc = L.rtfhe_tlwe_phase(C.byref(params), _ptr(key0), _ptr(cts), _ptr(ph), cts.shape[0])
+    if rc != 0:
+        raise RtfheError(rc, "rtfhe_tlwe_phase failed")
+    return ph
