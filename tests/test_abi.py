@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rtfhe.h declares, fails loudly without a GPU,
+and its host-side (non-GPU) entry points behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    import rustfhe_amd as R
+    lib = R.load()
+    hdr = open(os.path.join(ROOT, "include", "rtfhe.h")).read()
+    declared = set(re.findall(r"\b(rtfhe_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "include/rtfhe.h declares %s but librtfhe_hip.so does not export it" % sym
+    assert declared == set(R._ffi.EXPORTED_SYMBOLS), declared ^ set(R._ffi.EXPORTED_SYMBOLS)
+
+
+def test_library_is_a_gfx950_code_object():
+    import rustfhe_amd as R
+    R.load()
+    blob = open(R._ffi.lib_path(), "rb").read()
+    assert b"gfx950" in blob and b"k_bootstrap" in blob
+
+
+def test_no_cpu_fallback_without_device():
+    import rustfhe_amd as R
+    if R.load().rtfhe_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(R.RtfheError) as ei:
+        R.Engine(R.Params())
+    assert ei.value.code == R._ffi.ERR_NO_DEVICE and "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "rustfhe_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import orc" not in txt and "liboracle" not in txt and "tfhe_oracle" not in txt, f
+
+
+def test_bad_params_rejected():
+    import rustfhe_amd as R
+    lib = R.load()
+    h = C.c_void_p()
+    for bad in (R.Params(N=512), R.Params(l=2, bgbit=10), R.Params(n=0), R.Params(n=5000), R.Params(N=1024, nbit=11)):
+        assert lib.rtfhe_ctx_create(C.byref(bad), 0, C.byref(h)) in (R._ffi.ERR_INVALID, R._ffi.ERR_NO_DEVICE)
+        assert not h.value
+    assert lib.rtfhe_ctx_create(None, 0, C.byref(h)) == R._ffi.ERR_INVALID
+
+
+def test_host_keygen_encrypt_decrypt_roundtrip():
+    import rustfhe_amd as R
+    p = R.Params(n=40)
+    key0, key1, bk, ksk = R.keygen(p, 5, want_bk=False, want_ksk=True)
+    assert set(np.unique(key0)) <= {0, 1} and set(np.unique(key1)) <= {0, 1} and len(key1) == p.N
+    bits = np.array([0, 1, 1, 0, 1], np.uint8)
+    ct = R.encrypt_bits(p, key0, bits, 9)
+    assert ct.shape == (5, p.n + 1)
+    assert np.array_equal(R.decrypt_bits(p, key0, ct), bits)
+    ph = R.phases(p, key0, ct).astype(np.int64)
+    exp = np.where(bits == 1, 0x20000000, 0xE0000000)
+    assert np.abs(((ph - exp + 2 ** 31) % 2 ** 32) - 2 ** 31).max() < 2 ** 21       # sigma = 2^-15 -> 2^17 LSB
+    # key-switch key rows decrypt to t * s_i * 2^(32 - 2(l+1))  (hom_nand/src/tlwe.rs:252-274)
+    rows = ksk.reshape(p.N, p.ks_t, 3, p.n + 1)
+    for (i, l, d) in [(0, 0, 0), (3, 2, 1), (17, 7, 2)]:
+        got = int(R.phases(p, key0, rows[i, l, d][None])[0])
+        want = (d + 1) * int(key1[i]) * (1 << (32 - 2 * (l + 1))) % 2 ** 32
+        assert abs(((got - want + 2 ** 31) % 2 ** 32) - 2 ** 31) < 2 ** 21
+    # same seed -> same keys
+    k0b, _, _, _ = R.keygen(p, 5, want_bk=False, want_ksk=False)
+    assert np.array_equal(key0, k0b)
+
+
+def test_host_bk_is_a_valid_trgsw_set(orc):
+    """BK rows produced by the product's keygen decrypt (with the oracle as checker) to mu * 2^(32-6(i+1)) gadget rows."""
+    import rustfhe_amd as R
+    p = R.Params(n=3)
+    key0, key1, bk, _ = R.keygen(p, 11, want_ksk=False)
+    bk = bk.reshape(p.n, 2, 6, p.N)
+    pl = orc.Plan(p.N)
+    for i in range(p.n):
+        for j in range(6):
+            ct = np.concatenate([bk[i, 0, j], bk[i, 1, j]])
+            ph = np.empty(p.N, np.uint32)
+            orc.lib().orc_trlwe_phase(pl.h, p.N, key1.ctypes.data_as(C.POINTER(C.c_int32)), ct.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      ph.ctypes.data_as(C.POINTER(C.c_uint32)))
+            want = np.zeros(p.N, np.int64)
+            g = int(key0[i]) << (32 - 6 * ((j % 3) + 1))
+            if j < 3:
+                want[0] = g                                # cipher[j] += mu / Bg^(j+1)
+            else:
+                # p_key[j] += g  <=>  phase = b - a*s gains  -g * s(X)
+                want = (-g * key1.astype(np.int64)) % 2 ** 32
+            err = ((ph.astype(np.int64) - want + 2 ** 31) % 2 ** 32) - 2 ** 31
+            assert np.abs(err).max() < 2 ** 12, (i, j)
