@@ -118,6 +118,8 @@ int rtfhe_fft_u32_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, uint
 /* ---- key generation / encryption (host side; own seeded generator, the reference's is thread_rng) ---- */
 int rtfhe_keygen(const rtfhe_params *p, uint64_t seed, int32_t *key0 /* [n] */, int32_t *key1 /* [N] */,
                  uint32_t *bk /* [n][2][2l][N] */, uint32_t *ksk /* [N][t][base-1][n+1] */);
+int rtfhe_keygen_with_keys(const rtfhe_params *p, uint64_t seed, const int32_t *key0, const int32_t *key1,
+                           uint32_t *bk, uint32_t *ksk);    /* TFHE::new for caller-supplied secret keys */
 int rtfhe_tlwe_encrypt_bits(const rtfhe_params *p, const int32_t *key0, uint64_t seed,
                             const uint8_t *bits, uint32_t *out /* [count][n+1] */, size_t count);
 int rtfhe_tlwe_decrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint32_t *in,

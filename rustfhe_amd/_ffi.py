@@ -58,6 +58,7 @@ _SIGNATURES = {
     "rtfhe_ifft_i32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_fft_u32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_keygen": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_keygen_with_keys": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_tlwe_decrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_tlwe_phase": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

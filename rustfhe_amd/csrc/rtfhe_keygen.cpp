@@ -83,10 +83,19 @@ extern "C" {
 
 int rtfhe_keygen(const rtfhe_params* p, uint64_t seed, int32_t* key0, int32_t* key1, uint32_t* bk, uint32_t* ksk) {
     if (!valid(p) || !key0 || !key1) return RTFHE_ERR_INVALID;
-    const int n = p->n, N = p->N, l = p->l, rows = 2 * l;
     Rng root(seed);
-    for (int i = 0; i < n; i++) key0[i] = (int32_t)(root.next() >> 63);
-    for (int i = 0; i < N; i++) key1[i] = (int32_t)(root.next() >> 63);
+    for (int i = 0; i < p->n; i++) key0[i] = (int32_t)(root.next() >> 63);
+    for (int i = 0; i < p->N; i++) key1[i] = (int32_t)(root.next() >> 63);
+    return rtfhe_keygen_with_keys(p, root.next(), key0, key1, bk, ksk);
+}
+
+// TFHE::new(s_key_tlwelv0, s_key_tlwelv1) (hom_nand/src/tfhe.rs:21-25): key material for caller-supplied secret keys
+int rtfhe_keygen_with_keys(const rtfhe_params* p, uint64_t seed, const int32_t* key0, const int32_t* key1, uint32_t* bk, uint32_t* ksk) {
+    if (!valid(p) || !key0 || !key1) return RTFHE_ERR_INVALID;
+    const int n = p->n, N = p->N, l = p->l, rows = 2 * l;
+    for (int i = 0; i < n; i++) if (key0[i] != 0 && key0[i] != 1) return RTFHE_ERR_INVALID;
+    for (int i = 0; i < N; i++) if (key1[i] != 0 && key1[i] != 1) return RTFHE_ERR_INVALID;
+    Rng root(seed);
     const float alpha_bk = 1.0f / 33554432.0f;   // 2^-25, trlwe.rs:77
     const float alpha_ks = 1.0f / 32768.0f;      // 2^-15, tlwe.rs:176
     const unsigned hw = std::thread::hardware_concurrency();

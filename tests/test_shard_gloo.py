@@ -1,0 +1,88 @@
+"""CPU, world_size 2, gloo: the scatter -> per-rank bootstrap -> gather flow of rustfhe_amd/shard.py.  The per-rank
+compute here is the CPU oracle on a small parameter set (tests may use the oracle as a stand-in checker; on a GPU
+node the callback is shard.engine_compute)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, count, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import orc
+    from rustfhe_amd.shard import ShardedGates, partition
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = orc.Params(n=5)
+    K = orc.Keys(P, 321)            # same seed on every rank = replicated keys
+    pl = orc.Plan(P.N)
+
+    def compute(op, a, b):
+        a = a.numpy().view(np.uint32)
+        b = a if b is None else b.numpy().view(np.uint32)
+        out = np.stack([orc.gate(P, pl, op, K.bk_f, None, K.ksk, x, y) for x, y in zip(a, b)])
+        return torch.from_numpy(out.view(np.int32))
+
+    sg = ShardedGates(compute, P.n + 1, torch.device("cpu"))
+    in0 = in1 = None
+    bits = None
+    if rank == 0:
+        rng = np.random.default_rng(7)
+        bits = (rng.integers(0, 2, count), rng.integers(0, 2, count))
+        in0 = torch.from_numpy(K.encrypt_bits(bits[0]).view(np.int32))
+        in1 = torch.from_numpy(K.encrypt_bits(bits[1]).view(np.int32))
+    out = sg.run(orc.NAND, in0, in1, count)
+    res = None
+    if rank == 0:
+        o = out.numpy().view(np.uint32)
+        exp = np.stack([orc.gate(P, pl, orc.NAND, K.bk_f, None, K.ksk, x, y)
+                        for x, y in zip(in0.numpy().view(np.uint32), in1.numpy().view(np.uint32))])
+        res = (bool(np.array_equal(o, exp)), K.decrypt_bits(o) == list(1 - (bits[0] & bits[1])), partition(count, world))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        q.put(res)
+
+
+@pytest.mark.parametrize("count", [7, 2, 1])
+def test_scatter_bootstrap_gather_world2(count):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, count, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    same, dec_ok, parts = res
+    assert same and dec_ok
+    assert parts[0][0] == 0 and parts[-1][1] == count and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+def test_partition_properties():
+    from rustfhe_amd.shard import partition
+    for count in (0, 1, 5, 1024, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            p = partition(count, world)
+            sizes = [e - b for b, e in p]
+            assert sum(sizes) == count and max(sizes) - min(sizes) <= 1 and p[0][0] == 0 and p[-1][1] == count
