@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -160,6 +161,8 @@ struct rtfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
+    int num_cus = 256;
+    int force_waves = 0;   // RTFHE_FORCE_WAVES=4|8 (tuning knob)
     std::string err;
 };
 
@@ -200,9 +203,8 @@ int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
     return 0;
 }
 
-template <int LOGN>
-int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    constexpr int W = (LOGN == 10) ? 4 : 2;
+template <int LOGN, int W>
+int launch_bootstrap_w(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     auto k = k_bootstrap<LOGN, 3, 6, 8, 2, KSQ, W>;
     const size_t lds = bootstrap_lds_bytes<LOGN>(W, a.npad);
     if (int rc = allow_lds(ctx, k, lds)) return rc;
@@ -211,6 +213,19 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     HIPCHECK(ctx, hipGetLastError());
     ctx->launches++;
     return 0;
+}
+
+// Workgroup shape: one wave per gate.  Up to 4 gates per CU (<= 1024 gates on 256 CUs) a 4-wave workgroup per CU
+// spreads the batch over every CU; beyond that 8-wave workgroups (2 waves per SIMD) keep twice as many gates resident.
+template <int LOGN>
+int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    if constexpr (LOGN == 10) {
+        const int force = ctx->force_waves;
+        if (force == 8 || (force == 0 && a.count > 4 * ctx->num_cus)) return launch_bootstrap_w<10, 8>(ctx, a, s);
+        return launch_bootstrap_w<10, 4>(ctx, a, s);
+    } else {
+        return launch_bootstrap_w<11, 2>(ctx, a, s);
+    }
 }
 
 int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
@@ -231,7 +246,7 @@ template <int LOGN>
 int launch_fft_t(rtfhe_ctx* ctx, bool forward, FftArgs a, hipStream_t s) {
     constexpr int W = 4;
     typedef Geo<LOGN> G;
-    const size_t lds = (size_t)(G::TW_DIR + W * G::XSLOTS) * sizeof(cplx);
+    const size_t lds = (size_t)G::TW_DIR * sizeof(cplx) + (size_t)W * G::XSLOTS * sizeof(double);
     int grid = (a.count + W - 1) / W;
     if (grid > 2048) grid = 2048;
     if (forward) {
@@ -328,6 +343,11 @@ int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
     ctx->ksw = (p->n + 1 + 3) / 4 * 4;
     ctx->tw.build(p->N);
     int rc = use(ctx);
+    if (!rc) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
+        if (const char* e = std::getenv("RTFHE_FORCE_WAVES")) ctx->force_waves = std::atoi(e);
+    }
     if (!rc) rc = upload_twiddles(ctx);
     if (!rc && hipStreamCreate(&ctx->stream) != hipSuccess) rc = fail(ctx, RTFHE_ERR_HIP, "hipStreamCreate failed");
     if (!rc && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess))

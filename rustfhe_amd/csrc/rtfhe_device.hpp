@@ -43,7 +43,7 @@ struct Geo {
     static constexpr int TW_P3 = TW_P2 + (R - 1) * NLOW;       // [NLOW-4]  (stages with halfnn >= 4 left for pass 3)
     static constexpr int TW_DIR = TW_P3 + (NLOW - 4);          // cplx per direction
     static constexpr int TW_TOTAL = 2 * TW_DIR;                // forward then inverse
-    // LDS exchange buffer, cplx slots
+    // LDS exchange buffer, slots of one double (real and imaginary halves take turns)
     static constexpr int XSLOTS = P + 64;
     __host__ __device__ static constexpr int f1(int pos) { return pos + NLOW * (pos >> 6); }   // L1 <-> L2
     __host__ __device__ static constexpr int f2(int pos) { return pos + (pos >> LR); }         // L2 <-> L3
@@ -66,13 +66,21 @@ __device__ __forceinline__ void wave_lds_sync() {
 // butterflies (one register-index bit MB at a time; h = 1 << MB; q = m & (h-1) selects the twiddle)
 // ---------------------------------------------------------------------------------------------
 
+// All twiddles of one in-register pass, loaded from LDS ahead of use so that their latency overlaps the
+// previous pass / exchange.  Entry R - 2h + q belongs to the stage with h = 1 << MB, q = m & (h - 1).
+template <int CNT>
+struct Tw {
+    cplx w[CNT > 0 ? CNT : 1];
+    __device__ __forceinline__ void load(const cplx* __restrict__ tw, int stride) {
+#pragma unroll
+        for (int e = 0; e < CNT; e++) w[e] = tw[e * stride];
+    }
+};
+
 // DIF, twiddled: x0' = x0 + x1 ; x1' = (x0 - x1) * w      (spqlios-fft-impl.cpp:546-569)
 template <int R, int MB>
-__device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], const cplx* __restrict__ tw, int stride) {
+__device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], const cplx* w) {
     constexpr int h = 1 << MB;
-    cplx w[h];
-#pragma unroll
-    for (int q = 0; q < h; q++) w[q] = tw[q * stride];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         if (m & h) continue;
@@ -89,11 +97,8 @@ __device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], c
 
 // DIT, twiddled: t = x1 * w ; x0' = x0 + t ; x1' = x0 - t   (spqlios-fft-impl.cpp:346-359)
 template <int R, int MB>
-__device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], const cplx* __restrict__ tw, int stride) {
+__device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], const cplx* w) {
     constexpr int h = 1 << MB;
-    cplx w[h];
-#pragma unroll
-    for (int q = 0; q < h; q++) w[q] = tw[q * stride];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         if (m & h) continue;
@@ -143,52 +148,50 @@ __device__ __forceinline__ void inv_stage_size4(double (&re)[R], double (&im)[R]
 
 // (re,im) * (c,s):  re*c - im*s , im*c + re*s   (spqlios-fft-impl.cpp:512-517, 390-395)
 template <int R>
-__device__ __forceinline__ void twist_mul(double (&re)[R], double (&im)[R], const cplx* __restrict__ tw) {
+__device__ __forceinline__ void twist_mul(double (&re)[R], double (&im)[R], const cplx* w) {
 #pragma unroll
     for (int m = 0; m < R; m++) {
-        const cplx w = tw[m * 64];
-        const double rc = re[m] * w.x, ic = im[m] * w.x, rs = re[m] * w.y, is = im[m] * w.y;
+        const double rc = re[m] * w[m].x, ic = im[m] * w[m].x, rs = re[m] * w[m].y, is = im[m] * w[m].y;
         re[m] = rc - is;
         im[m] = ic + rs;
     }
 }
 
-template <int R, int LR, int MBTOP>
-struct P12 {   // passes 1 and 2: all LR register bits, twiddled
-    __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* tw, int stride) {
-        // stage MB uses entries [R - 2h, R - h) of the pass table
+template <int R, int MBTOP>
+struct P12 {   // passes 1 and 2: all LR register bits, twiddled; w = the pass's R-1 twiddles
+    __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 0) {
             constexpr int h = 1 << MBTOP;
-            fwd_stage_tw<R, MBTOP>(re, im, tw + (R - 2 * h) * stride, stride);
-            P12<R, LR, MBTOP - 1>::fwd(re, im, tw, stride);
+            fwd_stage_tw<R, MBTOP>(re, im, w + (R - 2 * h));
+            P12<R, MBTOP - 1>::fwd(re, im, w);
         }
     }
-    __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* tw, int stride) {
+    __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 0) {
             constexpr int h = 1 << MBTOP;
-            P12<R, LR, MBTOP - 1>::inv(re, im, tw, stride);
-            inv_stage_tw<R, MBTOP>(re, im, tw + (R - 2 * h) * stride, stride);
+            P12<R, MBTOP - 1>::inv(re, im, w);
+            inv_stage_tw<R, MBTOP>(re, im, w + (R - 2 * h));
         }
     }
 };
 
 template <int R, int NLOW, int MBTOP>
 struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uniform twiddles), bits 1, 0 special
-    __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* tw) {
+    __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 2) {
             constexpr int h = 1 << MBTOP;
-            fwd_stage_tw<R, MBTOP>(re, im, tw + (NLOW - 2 * h), 1);
-            P3<R, NLOW, MBTOP - 1>::fwd(re, im, tw);
+            fwd_stage_tw<R, MBTOP>(re, im, w + (NLOW - 2 * h));
+            P3<R, NLOW, MBTOP - 1>::fwd(re, im, w);
         } else {
             fwd_stage_size4<R>(re, im);
             stage_size2<R>(re, im);
         }
     }
-    __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* tw) {
+    __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 2) {
             constexpr int h = 1 << MBTOP;
-            P3<R, NLOW, MBTOP - 1>::inv(re, im, tw);
-            inv_stage_tw<R, MBTOP>(re, im, tw + (NLOW - 2 * h), 1);
+            P3<R, NLOW, MBTOP - 1>::inv(re, im, w);
+            inv_stage_tw<R, MBTOP>(re, im, w + (NLOW - 2 * h));
         } else {
             stage_size2<R>(re, im);
             inv_stage_size4<R>(re, im);
@@ -196,55 +199,86 @@ struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uni
     }
 };
 
-// Forward transform.  in: layout L1 (re[m], im[m] = point lane + 64 m), not yet twisted.
-// out: layout L3 (point (lane << LR) | m), the FrrSeries "native order" of the reference.
-// tw: LDS, forward table.  xbuf: LDS, wave-private, Geo::XSLOTS slots.
-template <int LOGN>
-__device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                            const cplx* __restrict__ tw, cplx* __restrict__ xbuf, int lane) {
+// Wave-private exchange of the 2R doubles a lane holds (R real parts, then R imaginary parts) through a
+// buffer of Geo::XSLOTS doubles: slot maps FROM (written layout) and TO (read layout).  Real and imaginary
+// halves go through the same buffer one after the other (half the LDS footprint of a cplx buffer at the same
+// LDS cycle count: ds_write_b64 / ds_read_b64 move 8 B per lane per 6 / 2 cycles vs 16 B per 13 / 4).
+template <int LOGN, int FROM, int TO>
+__device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
+                                         double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
-    twist_mul<R>(re, im, tw + G::TW_TWIST + lane);
-    P12<R, G::LR, G::LR - 1>::fwd(re, im, tw + G::TW_P1 + lane, 64);
+    auto slot = [&](int layout, int m) {
+        // the pad map is the one of the exchange (f1 for L1<->L2, f2 for L2<->L3), the position the one of the layout
+        const int pos = layout == 1 ? G::pos1(lane, m) : layout == 2 ? G::pos2(lane, m) : G::pos3(lane, m);
+        return (FROM + TO == 3) ? G::f1(pos) : G::f2(pos);
+    };
 #pragma unroll
-    for (int m = 0; m < R; m++) xbuf[G::f1(G::pos1(lane, m))] = make_double2(re[m], im[m]);
+    for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f1(G::pos2(lane, m))]; re[m] = v.x; im[m] = v.y; }
-    P12<R, G::LR, G::LR - 1>::fwd(re, im, tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+    for (int m = 0; m < R; m++) re[m] = xbuf[slot(TO, m)];
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < R; m++) xbuf[G::f2(G::pos2(lane, m))] = make_double2(re[m], im[m]);
+    for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = im[m];
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f2(G::pos3(lane, m))]; re[m] = v.x; im[m] = v.y; }
-    P3<R, G::NLOW, G::LOW - 1>::fwd(re, im, tw + G::TW_P3);
+    for (int m = 0; m < R; m++) im[m] = xbuf[slot(TO, m)];
     wave_lds_sync();
+}
+
+// Forward transform in two parts so that a caller can issue global loads between them.
+// part A: twist, pass 1, exchange, pass 2.  in: layout L1 (re[m], im[m] = point lane + 64 m), not yet twisted.
+// part B: exchange, pass 3.                  out: layout L3 (point (lane << LR) | m) = the reference's FrrSeries order.
+// tw: LDS, forward table.  xbuf: LDS, wave-private, Geo::XSLOTS doubles.
+template <int LOGN>
+__device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
+                                              const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    typedef Geo<LOGN> G;
+    constexpr int R = G::R;
+    Tw<R> wt; Tw<R - 1> w1, w2;
+    wt.load(tw + G::TW_TWIST + lane, 64);
+    w1.load(tw + G::TW_P1 + lane, 64);
+    twist_mul<R>(re, im, wt.w);
+    P12<R, G::LR - 1>::fwd(re, im, w1.w);
+    w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);     // in flight during the exchange
+    exchange<LOGN, 1, 2>(re, im, xbuf, lane);
+    P12<R, G::LR - 1>::fwd(re, im, w2.w);
+}
+template <int LOGN>
+__device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
+                                              const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    typedef Geo<LOGN> G;
+    Tw<G::NLOW - 4> w3;
+    w3.load(tw + G::TW_P3, 1);
+    exchange<LOGN, 2, 3>(re, im, xbuf, lane);
+    P3<G::R, G::NLOW, G::LOW - 1>::fwd(re, im, w3.w);
+}
+template <int LOGN>
+__device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
+                                            const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    fft_forward_a<LOGN>(re, im, tw, xbuf, lane);
+    fft_forward_b<LOGN>(re, im, tw, xbuf, lane);
 }
 
 // Inverse transform.  in: layout L3, ALREADY scaled by 2/N.  out: layout L1, untwisted (natural
 // coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
 template <int LOGN>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                            const cplx* __restrict__ tw, cplx* __restrict__ xbuf, int lane) {
+                                            const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
-    P3<R, G::NLOW, G::LOW - 1>::inv(re, im, tw + G::TW_P3);
-#pragma unroll
-    for (int m = 0; m < R; m++) xbuf[G::f2(G::pos3(lane, m))] = make_double2(re[m], im[m]);
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f2(G::pos2(lane, m))]; re[m] = v.x; im[m] = v.y; }
-    P12<R, G::LR, G::LR - 1>::inv(re, im, tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < R; m++) xbuf[G::f1(G::pos2(lane, m))] = make_double2(re[m], im[m]);
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < R; m++) { const cplx v = xbuf[G::f1(G::pos1(lane, m))]; re[m] = v.x; im[m] = v.y; }
-    P12<R, G::LR, G::LR - 1>::inv(re, im, tw + G::TW_P1 + lane, 64);
-    twist_mul<R>(re, im, tw + G::TW_TWIST + lane);
-    wave_lds_sync();
+    Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1; Tw<R> wt;
+    w3.load(tw + G::TW_P3, 1);
+    P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
+    w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+    exchange<LOGN, 3, 2>(re, im, xbuf, lane);
+    P12<R, G::LR - 1>::inv(re, im, w2.w);
+    w1.load(tw + G::TW_P1 + lane, 64);
+    exchange<LOGN, 2, 1>(re, im, xbuf, lane);
+    wt.load(tw + G::TW_TWIST + lane, 64);
+    P12<R, G::LR - 1>::inv(re, im, w1.w);
+    twist_mul<R>(re, im, wt.w);
 }
 
 // Torus32(int64_t(x)): truncate toward zero, keep the low 32 bits (fft_processor_spqlios.cpp:182).
@@ -268,10 +302,10 @@ __host__ __device__ constexpr uint32_t decomp_mask(int l, int bits) {
     return u;
 }
 
-// digit j of the pre-masked word u = (x + M) ^ M, sign-extended from `bits` (utils/src/math.rs:314-322)
+// digit j of the pre-masked word u = (x + M) ^ M, sign-extended from `bits` (utils/src/math.rs:314-322):
+// (v & half) * 0xfffffffe + v  ==  v - 2 (v & half)  ==  the two's-complement value of the `bits`-wide field
 __device__ __forceinline__ int32_t decomp_digit(uint32_t u, int bits, int j) {
-    const uint32_t v = (u >> (32 - bits * (j + 1))) & ((1u << bits) - 1u);
-    return (int32_t)((v & (1u << (bits - 1))) * 0xfffffffeu + v);
+    return __builtin_amdgcn_sbfe((int32_t)u, (uint32_t)(32 - bits * (j + 1)), (uint32_t)bits);
 }
 
 // negacyclic rotate read: coefficient c of X^r * p, p in LDS (utils/src/math.rs:85-132)

@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1
 template <int LOGN, int L, int BGBIT, bool CMUX>
 __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, const cplx* __restrict__ bk_i,
                                           const cplx* __restrict__ twf, const cplx* __restrict__ twi,
-                                          cplx* __restrict__ xbuf, int lane) {
+                                          double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
     constexpr int N = G::N, P = G::P, R = G::R;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
@@ -77,16 +77,21 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
             const cplx* bkj = bk_i + (size_t)((h * L + jj) * 2) * R * 64 + lane;
-            cplx b0[R], b1[R];
-#pragma unroll
-            for (int m = 0; m < R; m++) { b0[m] = bkj[m * 64]; b1[m] = bkj[(R + m) * 64]; }
             double re[R], im[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 re[m] = (double)decomp_digit(u[m], BGBIT, jj);
                 im[m] = (double)decomp_digit(u[R + m], BGBIT, jj);
             }
-            fft_forward<LOGN>(re, im, twf, xbuf, lane);
+            fft_forward_a<LOGN>(re, im, twf, xbuf, lane);
+            // the two BK rows of this digit are requested here, not earlier: their 64 VGPRs would otherwise be
+            // live through the whole transform; the last exchange + in-register pass cover the L2 latency
+            __builtin_amdgcn_sched_barrier(0);
+            cplx b0[R], b1[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) { b0[m] = bkj[m * 64]; b1[m] = bkj[(R + m) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+            fft_forward_b<LOGN>(re, im, twf, xbuf, lane);
             // hadamard + fold-add from zero, utils/src/spqlios.rs:204-222, hom_nand/src/trgsw.rs:290-299
 #pragma unroll
             for (int m = 0; m < R; m++) {
@@ -137,10 +142,11 @@ __device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ apr
     constexpr int BASE1 = (1 << KS_BB) - 1;
     constexpr uint32_t ROUND = (32 - KS_T * KS_BB) != 0 ? (1u << (32 - KS_T * KS_BB - 1)) : 0u;
     const int zero_row = N * KS_T * BASE1;
+    // lanes past the end of a row re-read its last 16 bytes (branch-free); the columns they accumulate are never stored
     uint4 sum[KSQ];
-    bool act[KSQ];
+    int idx[KSQ];
 #pragma unroll
-    for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); act[q] = 4 * (lane + 64 * q) < ksw; }
+    for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); idx[q] = min(lane + 64 * q, ksw / 4 - 1); }
 #pragma unroll 1
     for (int i = 0; i < N; i++) {
         const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(aprime[i] + ROUND));
@@ -151,7 +157,7 @@ __device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ apr
             const int row = d ? ((i * KS_T + l) * BASE1 + (int)d - 1) : zero_row;
             const uint4* p = reinterpret_cast<const uint4*>(ksk + (size_t)row * ksw);
 #pragma unroll
-            for (int q = 0; q < KSQ; q++) v[l][q] = act[q] ? p[lane + 64 * q] : make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < KSQ; q++) v[l][q] = p[idx[q]];
         }
 #pragma unroll
         for (int l = 0; l < KS_T; l++)
@@ -172,7 +178,7 @@ __device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ apr
 
 template <int LOGN>
 __host__ __device__ constexpr size_t bootstrap_wave_lds_bytes(int npad) {
-    return (size_t)Geo<LOGN>::XSLOTS * sizeof(cplx) + (size_t)2 * Geo<LOGN>::N * 4 + (size_t)npad * 4;
+    return (size_t)Geo<LOGN>::XSLOTS * sizeof(double) + (size_t)2 * Geo<LOGN>::N * 4 + (size_t)npad * 4;
 }
 template <int LOGN>
 __host__ __device__ constexpr size_t bootstrap_lds_bytes(int waves, int npad) {
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
     if (g >= a.count) return;
 
     unsigned char* wbase = smem + (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(a.npad);
-    cplx* xbuf = reinterpret_cast<cplx*>(wbase);
-    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(cplx));
+    double* xbuf = reinterpret_cast<double*>(wbase);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(double));
     uint32_t* abar = accbuf + 2 * N;
     const cplx* twf = tw;
     const cplx* twi = tw + G::TW_DIR;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_forward(const FftArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int idx = tid; idx < G::TW_DIR; idx += 64 * WAVES) tw[idx] = a.tw[idx];
     __syncthreads();
-    cplx* xbuf = tw + G::TW_DIR + (size_t)wave * G::XSLOTS;
+    double* xbuf = reinterpret_cast<double*>(tw + G::TW_DIR) + (size_t)wave * G::XSLOTS;
     for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
         const int32_t* src = reinterpret_cast<const int32_t*>(a.src) + (size_t)g * N;
         double re[R], im[R];
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_inverse(const FftArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int idx = tid; idx < G::TW_DIR; idx += 64 * WAVES) tw[idx] = a.tw[G::TW_DIR + idx];
     __syncthreads();
-    cplx* xbuf = tw + G::TW_DIR + (size_t)wave * G::XSLOTS;
+    double* xbuf = reinterpret_cast<double*>(tw + G::TW_DIR) + (size_t)wave * G::XSLOTS;
     const double scale = 2.0 / (double)N;
     for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
         const double* src = reinterpret_cast<const double*>(a.src) + (size_t)g * N;
@@ -371,8 +377,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_external_product(const ExtPro
     const int g = blockIdx.x * WAVES + wave;
     if (g >= a.count) return;
     unsigned char* wbase = smem + (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(0);
-    cplx* xbuf = reinterpret_cast<cplx*>(wbase);
-    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(cplx));
+    double* xbuf = reinterpret_cast<double*>(wbase);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(double));
     for (int c = lane; c < 2 * N; c += 64) accbuf[c] = a.trlwe[(size_t)g * 2 * N + c];
     wave_lds_sync();
     const size_t trgsw_cplx = (size_t)2 * L * 2 * R * 64;
