@@ -261,7 +261,7 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
     fft_forward_b<LOGN>(re, im, tw, xbuf, lane);
 }
 
-// Inverse transform.  in: layout L3, ALREADY scaled by 2/N.  out: layout L1, untwisted (natural
+// Inverse transform.  in: layout L3, unscaled (the 2/N factor lives in the untwist twiddles).  out: layout L1, untwisted (natural
 // coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
 template <int LOGN>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],

@@ -109,14 +109,14 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
         }
     }
 
-    const double scale = 2.0 / (double)N;   // fft_processor_spqlios.cpp:158
+    // the 2/N input scaling of the reference (fft_processor_spqlios.cpp:158) is folded into the untwist twiddles
 #pragma unroll 1
     for (int comp = 0; comp < 2; comp++) {
         double re[R], im[R];
 #pragma unroll
         for (int m = 0; m < R; m++) {
-            re[m] = (comp ? s1re[m] : s0re[m]) * scale;
-            im[m] = (comp ? s1im[m] : s0im[m]) * scale;
+            re[m] = comp ? s1re[m] : s0re[m];
+            im[m] = comp ? s1im[m] : s0im[m];
         }
         fft_inverse<LOGN>(re, im, twi, xbuf, lane);
         uint32_t* poly = accbuf + comp * N;
@@ -321,12 +321,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_inverse(const FftArgs a) 
     for (int idx = tid; idx < G::TW_DIR; idx += 64 * WAVES) tw[idx] = a.tw[G::TW_DIR + idx];
     __syncthreads();
     double* xbuf = reinterpret_cast<double*>(tw + G::TW_DIR) + (size_t)wave * G::XSLOTS;
-    const double scale = 2.0 / (double)N;
     for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
         const double* src = reinterpret_cast<const double*>(a.src) + (size_t)g * N;
-        double re[R], im[R];
+        double re[R], im[R];   // 2/N is folded into the untwist twiddles
 #pragma unroll
-        for (int m = 0; m < R; m++) { re[m] = src[G::pos3(lane, m)] * scale; im[m] = src[P + G::pos3(lane, m)] * scale; }
+        for (int m = 0; m < R; m++) { re[m] = src[G::pos3(lane, m)]; im[m] = src[P + G::pos3(lane, m)]; }
         fft_inverse<LOGN>(re, im, tw, xbuf, lane);
         uint32_t* dst = reinterpret_cast<uint32_t*>(a.dst) + (size_t)g * N;
 #pragma unroll

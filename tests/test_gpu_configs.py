@@ -1,0 +1,83 @@
+"""GPU: the remaining BASELINE.json configurations at (or at the per-GPU share of) their full sizes.
+config 3: 65,536 gates over 8 GPUs = 8,192 per GPU -> one 8,192-gate launch here (8-wave workgroups, 2 waves/SIMD)
+config 5: N = 2048 (NBIT = 11), l = 3 -- not a reference parameter set; parity is against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_per_gpu_shard_8192(engine, orc, params, keys):
+    import rustfhe_amd as R
+    G = 8192
+    rng = np.random.default_rng(33)
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    out = engine.gate_batch(R.NAND, c0, c1)
+    assert keys.decrypt_bits(out) == list(1 - (b0 & b1))
+    # determinism and gate independence at full size: a permuted batch gives the permuted outputs, bit for bit
+    perm = rng.permutation(G)
+    out_p = engine.gate_batch(R.NAND, c0[perm], c1[perm])
+    assert np.array_equal(out_p, out[perm])
+    # bit-exact against the oracle on a random sample (all 8,192 on the CPU would take minutes)
+    pick = rng.choice(G, 128, replace=False)
+    exp, _ = orc.gate_batch_mt(params, orc.NAND, keys.bk_f, None, keys.ksk, c0[pick], c1[pick], nthreads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(out[pick], exp)
+    # the 4-wave and the 8-wave workgroup shapes are the same arithmetic: first 1,000 gates alone == inside the big launch
+    assert np.array_equal(engine.gate_batch(R.NAND, c0[:1000], c1[:1000]), out[:1000])
+
+
+@pytest.fixture(scope="module")
+def setup2048(orc):
+    import rustfhe_amd as R
+    P = orc.Params(N=2048)
+    K = orc.Keys(P, 2048)
+    e = R.Engine(R.Params(N=2048), 0)
+    e.load_bk_torus(K.bk_t)
+    e.load_ksk(K.ksk)
+    yield P, K, e
+    e.close()
+
+
+def test_config5_transforms_n2048(setup2048, orc):
+    P, K, e = setup2048
+    g = golden("fft_N2048.npz")
+    a, b = e.twiddles()
+    assert a.tobytes() == g["ifft_table"].tobytes() and b.tobytes() == g["fft_table"].tobytes()
+    assert e.ifft_i32_batch(g["fft_src"]).tobytes() == g["fft_fwd"].tobytes()
+    assert np.array_equal(e.fft_u32_batch(g["inv_src"]), g["inv_out"])
+    assert e.export_bk_fft().tobytes() == K.bk_f.tobytes()
+
+
+def test_config5_gates_n2048(setup2048, orc):
+    import rustfhe_amd as R
+    P, K, e = setup2048
+    pl = orc.Plan(P.N)
+    rng = np.random.default_rng(44)
+    trlwe = rng.integers(0, 2 ** 32, (5, 2 * P.N), dtype=np.uint64).astype(np.uint32)
+    idx = np.array([0, 1, 300, 634, 77], np.int32)
+    w = P.trgsw_words
+    exp = np.stack([orc.external_product(P, pl, K.bk_f[i * w:(i + 1) * w], None, t) for i, t in zip(idx, trlwe)])
+    assert np.array_equal(e.external_product_batch(idx, trlwe).reshape(exp.shape), exp)
+    b0, b1 = [0, 0, 1, 1, 1, 0], [0, 1, 0, 1, 1, 1]
+    c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
+    t = np.stack([orc.gate_linear(P, orc.NAND, x, y) for x, y in zip(c0[:3], c1[:3])])
+    acc = e.blind_rotate_batch(t, 5)
+    assert np.array_equal(acc.reshape(3, -1), np.stack([orc.blind_rotate(P, pl, K.bk_f, None, x, 5) for x in t]))
+    for op, tt in ((R.NAND, [1, 1, 1, 0, 0, 1]), (R.XOR, [0, 1, 1, 0, 0, 1])):
+        out = e.gate_batch(op, c0, c1)
+        assert K.decrypt_bits(out) == tt
+        exp = np.stack([orc.gate(P, pl, op, K.bk_f, None, K.ksk, x, y) for x, y in zip(c0, c1)])
+        assert np.array_equal(out, exp)
+    # a 1,024-gate batch at N = 2048 (BASELINE config 5): all decrypt, a sample is bit-exact
+    bb0, bb1 = rng.integers(0, 2, 1024), rng.integers(0, 2, 1024)
+    d0, d1 = K.encrypt_bits(bb0), K.encrypt_bits(bb1)
+    out = e.gate_batch(R.NAND, d0, d1)
+    assert K.decrypt_bits(out) == list(1 - (bb0 & bb1))
+    pick = rng.choice(1024, 48, replace=False)
+    exp, _ = orc.gate_batch_mt(P, orc.NAND, K.bk_f, None, K.ksk, d0[pick], d1[pick], nthreads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(out[pick], exp)
