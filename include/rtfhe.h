@@ -12,6 +12,7 @@
  *   rtfhe_load_ksk                   <- KeySwitchingKey(Vec<[[TLWERep;3];8]>) (hom_nand/src/tlwe.rs:243-245)
  *   rtfhe_gate_batch[_dev]           <- TFHE::hom_nand/and/or/xor/not (hom_nand/src/tfhe.rs:41-71), count gates at once
  *   rtfhe_mux_batch                  <- TFHE::hom_mux (tfhe.rs:27-40)
+ *   rtfhe_circuit_wave_dev           <- eval_logic_expr over impl Logip for TFHE (nander/src/lib.rs:40-89), one level at a time
  *   rtfhe_bootstrap_batch            <- TFHE::bootstrap (tfhe.rs:73-80)
  *   rtfhe_blind_rotate_batch         <- TFHE::blind_rotate with the gate test vector (tfhe.rs:81-113)
  *   rtfhe_external_product_batch     <- Cross for TRGSWRepF (hom_nand/src/trgsw.rs:264-306)
@@ -60,7 +61,8 @@ typedef struct {
 } rtfhe_params;
 
 typedef enum {
-    RTFHE_NAND = 0, RTFHE_AND = 1, RTFHE_OR = 2, RTFHE_XOR = 3, RTFHE_NOT = 4, RTFHE_COPY = 5
+    RTFHE_NAND = 0, RTFHE_AND = 1, RTFHE_OR = 2, RTFHE_XOR = 3, RTFHE_NOT = 4, RTFHE_COPY = 5,
+    RTFHE_ANDNY = 6   /* hom_and(-in0, in1): the second AND of hom_mux, hom_nand/src/tfhe.rs:34 */
 } rtfhe_gate;
 
 typedef enum {
@@ -99,6 +101,11 @@ int rtfhe_bootstrap_batch(rtfhe_ctx *ctx, const uint32_t *tlwe, uint32_t *out, s
 /* ---- the hot path: device buffers, asynchronous on `stream` (a hipStream_t, may be NULL) ---- */
 int rtfhe_gate_batch_dev(rtfhe_ctx *ctx, int op, const void *d_in0, const void *d_in1, void *d_out,
                          size_t count, void *stream);
+/* one dependency wave of a gate netlist (the build-side counterpart of nander's eager tree walk, nander/src/lib.rs:72-89):
+ * gate g reads rows idx0[g] and idx1[g] of the wire table d_wires (u32[num_wires][n+1]), applies ops[g] and writes row
+ * idx_out[g]; all four arrays are int32[count] in device memory.  Gates of one call must be independent. */
+int rtfhe_circuit_wave_dev(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0, const void *d_idx1,
+                           const void *d_idx_out, void *d_wires, size_t count, void *stream);
 int rtfhe_sync(rtfhe_ctx *ctx, void *stream);
 /* device-side timing of the launches enqueued by the *_dev calls between begin and end (HIP events on
  * `stream`); end returns total milliseconds and the number of kernel launches */

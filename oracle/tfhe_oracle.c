@@ -509,6 +509,7 @@ void orc_gate_linear(const orc_params *p, int op, const uint32_t *in0, const uin
     case ORC_OR:   for (int32_t k = 0; k <= n; k++) t[k] = in0[k] + in1[k]; t[n] += c8; break;
     case ORC_XOR:  for (int32_t k = 0; k <= n; k++) t[k] = (in0[k] + in1[k]) * 2u; t[n] += c4; break;
     case ORC_NOT:  for (int32_t k = 0; k <= n; k++) t[k] = 0u - in0[k]; break;
+    case ORC_ANDNY: for (int32_t k = 0; k <= n; k++) t[k] = in1[k] - in0[k]; t[n] -= c8; break;   /* hom_and(-c, in0), tfhe.rs:34 */
     default:       for (int32_t k = 0; k <= n; k++) t[k] = in0[k]; break;
     }
 }

@@ -46,7 +46,7 @@ typedef struct {
     int32_t ks_basebit; /* key-switch base bits         hom_nand/src/tlwe.rs:179  (2)    */
 } orc_params;
 
-enum { ORC_NAND = 0, ORC_AND = 1, ORC_OR = 2, ORC_XOR = 3, ORC_NOT = 4, ORC_COPY = 5 };
+enum { ORC_NAND = 0, ORC_AND = 1, ORC_OR = 2, ORC_XOR = 3, ORC_NOT = 4, ORC_COPY = 5, ORC_ANDNY = 6 };
 enum { ORC_BACKEND_FFT64_MIRROR = 0, ORC_BACKEND_EXACT_INT = 1, ORC_BACKEND_HOOK = 2 };
 
 void orc_default_params(orc_params *p);

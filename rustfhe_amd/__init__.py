@@ -3,8 +3,8 @@
 The product is the C-ABI shared library librtfhe_hip.so (include/rtfhe.h, rustfhe_amd/csrc/); this
 package is the thin Python host side above it.  There is no CPU fallback anywhere in the package.
 """
-from ._ffi import AND, COPY, NAND, NOT, OR, XOR, Params, load  # noqa: F401
+from ._ffi import AND, ANDNY, COPY, NAND, NOT, OR, XOR, Params, load  # noqa: F401
 from .engine import Engine, RtfheError, decrypt_bits, encrypt_bits, keygen, phases  # noqa: F401
 
 __all__ = ["Engine", "Params", "RtfheError", "keygen", "encrypt_bits", "decrypt_bits", "phases",
-           "NAND", "AND", "OR", "XOR", "NOT", "COPY", "load"]
+           "NAND", "AND", "OR", "XOR", "NOT", "COPY", "ANDNY", "load"]

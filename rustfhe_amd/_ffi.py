@@ -29,7 +29,7 @@ class Params(C.Structure):
         return self.N * self.ks_t * ((1 << self.ks_basebit) - 1) * (self.n + 1)
 
 
-NAND, AND, OR, XOR, NOT, COPY = range(6)
+NAND, AND, OR, XOR, NOT, COPY, ANDNY = range(7)
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
 _SIGNATURES = {
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "rtfhe_mux_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_gate_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rtfhe_circuit_wave_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rtfhe_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_timer_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -234,7 +234,8 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
 }
 
 int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
-                     size_t count, hipStream_t s) {
+                     size_t count, hipStream_t s, const int32_t* d_ops = nullptr, const int32_t* d_idx0 = nullptr,
+                     const int32_t* d_idx1 = nullptr, const int32_t* d_idx_out = nullptr) {
     if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
     if (mode == MODE_GATE && !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "key-switching key not loaded");
     if (count == 0) return 0;
@@ -244,6 +245,7 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.in0 = (const uint32_t*)d_in0; a.in1 = (const uint32_t*)(d_in1 ? d_in1 : d_in0); a.out = (uint32_t*)d_out;
     a.count = (int)count; a.op = op; a.n = ctx->p.n; a.steps = steps; a.mode = mode; a.ksw = ctx->ksw;
     a.npad = (ctx->p.n + 1 + 63) / 64 * 64;
+    a.ops = d_ops; a.idx0 = d_idx0; a.idx1 = d_idx1; a.idx_out = d_idx_out;
     return ctx->logn == 10 ? launch_bootstrap_t<10>(ctx, a, s) : launch_bootstrap_t<11>(ctx, a, s);
 }
 
@@ -453,9 +455,17 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
 
 int rtfhe_gate_batch_dev(rtfhe_ctx* ctx, int op, const void* d_in0, const void* d_in1, void* d_out, size_t count, void* stream) {
     if (int rc = use(ctx)) return rc;
-    if (op < RTFHE_NAND || op > RTFHE_COPY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
+    if (op < RTFHE_NAND || op > RTFHE_ANDNY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
     if (!d_in0 || !d_out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     return launch_bootstrap(ctx, op, MODE_GATE, ctx->p.n, d_in0, d_in1, d_out, count, (hipStream_t)stream);
+}
+
+int rtfhe_circuit_wave_dev(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, const void* d_idx1, const void* d_idx_out,
+                           void* d_wires, size_t count, void* stream) {
+    if (int rc = use(ctx)) return rc;
+    if (!d_ops || !d_idx0 || !d_idx1 || !d_idx_out || !d_wires) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    return launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, count, (hipStream_t)stream,
+                            (const int32_t*)d_ops, (const int32_t*)d_idx0, (const int32_t*)d_idx1, (const int32_t*)d_idx_out);
 }
 
 int rtfhe_sync(rtfhe_ctx* ctx, void* stream) {
@@ -505,7 +515,7 @@ static int run_host_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const
 
 int rtfhe_gate_batch(rtfhe_ctx* ctx, int op, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
     if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
-    if (op < RTFHE_NAND || op > RTFHE_COPY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
+    if (op < RTFHE_NAND || op > RTFHE_ANDNY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
     const bool unary = (op == RTFHE_NOT || op == RTFHE_COPY);
     if (!unary && !in1) return fail(ctx, RTFHE_ERR_INVALID, "binary gate needs two inputs");
     return run_host_bootstrap(ctx, op, MODE_GATE, ctx->p.n, in0, unary ? nullptr : in1, out, count, (size_t)ctx->p.n + 1);
@@ -521,20 +531,15 @@ int rtfhe_blind_rotate_batch(rtfhe_ctx* ctx, const uint32_t* tlwe, int32_t steps
     return run_host_bootstrap(ctx, RTFHE_COPY, MODE_BLIND_ROTATE, steps, tlwe, nullptr, acc, count, (size_t)2 * ctx->p.N);
 }
 
-// hom_mux (tfhe.rs:27-40): AND(c, in1), AND(-c, in0), then bootstrap(i1 + i0 + 1/8)
+// hom_mux (tfhe.rs:27-40): i1 = AND(c, in1); i0 = AND(-c, in0); bootstrap(i1 + i0 + 1/8) -- the last line is hom_or(i1, i0)
 int rtfhe_mux_batch(rtfhe_ctx* ctx, const uint32_t* c, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
     if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
     if (!c || !in0 || !in1 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
-    const size_t w = (size_t)ctx->p.n + 1, total = count * w;
-    std::vector<uint32_t> nc(total), i1(total), i0(total);
+    const size_t total = count * ((size_t)ctx->p.n + 1);
+    std::vector<uint32_t> i1(total), i0(total);
     if (int rc = rtfhe_gate_batch(ctx, RTFHE_AND, c, in1, i1.data(), count)) return rc;
-    for (size_t k = 0; k < total; k++) nc[k] = 0u - c[k];
-    if (int rc = rtfhe_gate_batch(ctx, RTFHE_AND, nc.data(), in0, i0.data(), count)) return rc;
-    for (size_t g = 0; g < count; g++) {
-        for (size_t k = 0; k < w; k++) nc[g * w + k] = i1[g * w + k] + i0[g * w + k];
-        nc[g * w + w - 1] += 0x20000000u;
-    }
-    return rtfhe_bootstrap_batch(ctx, nc.data(), out, count);
+    if (int rc = rtfhe_gate_batch(ctx, RTFHE_ANDNY, c, in0, i0.data(), count)) return rc;
+    return rtfhe_gate_batch(ctx, RTFHE_OR, i1.data(), i0.data(), out, count);
 }
 
 int rtfhe_external_product_batch(rtfhe_ctx* ctx, const int32_t* bk_index, const uint32_t* trlwe, uint32_t* out, size_t count) {

@@ -14,7 +14,7 @@
 
 namespace rtfhe {
 
-enum { OP_NAND = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3, OP_NOT = 4, OP_COPY = 5 };
+enum { OP_NAND = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3, OP_NOT = 4, OP_COPY = 5, OP_ANDNY = 6 };
 enum { MODE_GATE = 0, MODE_BLIND_ROTATE = 1 };
 
 struct BootstrapArgs {
@@ -31,6 +31,12 @@ struct BootstrapArgs {
     int32_t mode;
     int32_t ksw;             // padded KSK row width in u32 (multiple of 4)
     int32_t npad;            // per-wave LDS words reserved for the mod-switched mask (>= n+1)
+    // netlist mode (all null for a plain batch): gate g reads rows idx0[g], idx1[g] of in0 (the wire table), applies
+    // ops[g] and writes row idx_out[g] of out
+    const int32_t* ops;
+    const int32_t* idx0;
+    const int32_t* idx1;
+    const int32_t* idx_out;
 };
 
 // gate pre-step on one TLWE word (a-part: isb = false, b-part: isb = true), hom_nand/src/tfhe.rs:27-71
@@ -43,6 +49,7 @@ __device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1
         case OP_OR:   return (x0 + x1) + (isb ? c8 : 0u);
         case OP_XOR:  return (x0 + x1) * 2u + (isb ? c4 : 0u);
         case OP_NOT:  return 0u - x0;
+        case OP_ANDNY: return (x1 - x0) - (isb ? c8 : 0u);   // hom_and(-x0, x1), the second AND of hom_mux (tfhe.rs:34)
         default:      return x0;
     }
 }
@@ -211,11 +218,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
     const int n = a.n;
     // pre-step + mod switch (tfhe.rs:97, 107-108): b floor, a_i rounded, both to [0, 2N)
     {
-        const uint32_t* p0 = a.in0 + (size_t)g * (n + 1);
-        const uint32_t* p1 = a.in1 + (size_t)g * (n + 1);
+        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
+        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
+        const int op = a.ops ? a.ops[g] : a.op;
         constexpr int SH = 32 - LOGN - 1;
         for (int i = lane; i <= n; i += 64) {
-            const uint32_t t = gate_linear(a.op, p0[i], p1[i], i == n);
+            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
             abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
         }
     }
@@ -258,7 +266,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
         accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[mm] : (0u - av[mm]);
     }
     wave_lds_sync();
-    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n, a.out + (size_t)g * (n + 1), lane);
+    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n,
+                                            a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1), lane);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import AND, COPY, NAND, NOT, OR, XOR, Params  # noqa: F401
+from ._ffi import AND, ANDNY, COPY, NAND, NOT, OR, XOR, Params  # noqa: F401
 
 
 class RtfheError(RuntimeError):
@@ -120,6 +120,11 @@ class Engine:
     def gate_batch_dev(self, op, d_in0, d_in1, d_out, count, stream=None):
         self._ck(self.L.rtfhe_gate_batch_dev(self.h, op, self._dev(d_in0), self._dev(d_in1), self._dev(d_out),
                                              count, C.c_void_p(stream) if stream else None))
+
+    def circuit_wave_dev(self, d_ops, d_idx0, d_idx1, d_idx_out, d_wires, count, stream=None):
+        self._ck(self.L.rtfhe_circuit_wave_dev(self.h, self._dev(d_ops), self._dev(d_idx0), self._dev(d_idx1),
+                                               self._dev(d_idx_out), self._dev(d_wires), count,
+                                               C.c_void_p(stream) if stream else None))
 
     def sync(self, stream=None):
         self._ck(self.L.rtfhe_sync(self.h, C.c_void_p(stream) if stream else None))

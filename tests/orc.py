@@ -15,7 +15,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_PATH = os.path.join(ORACLE_DIR, "_ref", "libspqlios_ref.so")
 
-NAND, AND, OR, XOR, NOT, COPY = range(6)
+NAND, AND, OR, XOR, NOT, COPY, ANDNY = range(7)
 BACKEND_MIRROR, BACKEND_EXACT, BACKEND_HOOK = 0, 1, 2
 
 

@@ -1,0 +1,106 @@
+"""Gate-netlist front-end (BASELINE config 4).  CPU: grammar, levelisation and adder netlists on plain bits.
+GPU: the 8-bit ripple-carry adder as a NAND netlist run wave by wave, many replicas at once."""
+import numpy as np
+import pytest
+
+
+def test_parser_matches_reference_grammar():
+    from rustfhe_amd.circuit import parse_logic_expr
+    # nander/src/lib.rs:90-172: left-assoc, no precedence, '!' prefix, parentheses
+    cases = {"1": 1, "0": 0, "1&0": 0, "1|0": 1, "1^1": 0, "1$1": 0, "0$1": 1, "!0": 1, "!!1": 1,
+             "1&0|1": 1, "1|0&0": 0, "(1|0)&(1^0)": 1, "!(1&1)$1": 1, " 1 & ( 0 | ! 0 ) ": 1, "1^1^1": 1}
+    for text, want in cases.items():
+        net, _ = parse_logic_expr(text)
+        assert net.evaluate_plain([]) == [want], text
+    for bad, msg in {"": "this is none", "(1&0": "braket is not closed", "2": "invalid element", "1&": "this is none"}.items():
+        with pytest.raises(ValueError) as e:
+            parse_logic_expr(bad)
+        assert msg in str(e.value)
+
+
+def test_adder_netlists_on_plain_bits():
+    from rustfhe_amd.circuit import ripple_carry_adder
+    rng = np.random.default_rng(1)
+    for nand_only, gates_per_fa in ((True, 9), (False, 5)):
+        net = ripple_carry_adder(8, nand_only)
+        d = net.describe()
+        assert d["gates"] == 8 * gates_per_fa and d["inputs"] == 16 and sum(d["wave_sizes"]) == d["gates"]
+        for _ in range(200):
+            a, b = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+            bits = [(a >> i) & 1 for i in range(8)] + [(b >> i) & 1 for i in range(8)]
+            out = net.evaluate_plain(bits)
+            assert sum(v << i for i, v in enumerate(out)) == a + b
+    # levelisation respects dependencies
+    net = ripple_carry_adder(4, True)
+    level = {}
+    base = 2 + net.num_inputs
+    for li, wave in enumerate(net.levels()):
+        for g in wave:
+            level[base + g] = li + 1
+    for g, (op, a, b) in enumerate(net.gates):
+        assert level.get(a, 0) < level[base + g] and level.get(b, 0) < level[base + g]
+
+
+def test_mux_netlist_plain():
+    from rustfhe_amd.circuit import Netlist
+    net = Netlist()
+    c, x, y = net.inputs(3)
+    net.output(net.mux(c, x, y))
+    for bits in range(8):
+        cb, xb, yb = bits & 1, (bits >> 1) & 1, (bits >> 2) & 1
+        assert net.evaluate_plain([cb, xb, yb]) == [yb if cb else xb]
+    assert net.describe()["depth"] == 2
+
+
+@pytest.mark.gpu
+def test_repl_expressions_on_gpu(engine, keys):
+    from rustfhe_amd.circuit import eval_logic_expr
+    for text, want in {"1$1": 0, "(1|0)&!(1^1)": 1, "!(0$0)": 0, "1": 1}.items():
+        ct = eval_logic_expr(engine, text)
+        assert keys.decrypt_bits([ct]) == [want], text
+
+
+@pytest.mark.gpu
+def test_ripple_carry_adder_8bit_waves(engine, orc, params, keys):
+    import rustfhe_amd as R
+    from rustfhe_amd.circuit import CircuitRunner, ripple_carry_adder
+    net = ripple_carry_adder(8, nand_only=True)
+    reps = 32
+    rng = np.random.default_rng(8)
+    A, B = rng.integers(0, 256, reps), rng.integers(0, 256, reps)
+    bits = np.array([[(a >> i) & 1 for i in range(8)] + [(b >> i) & 1 for i in range(8)] for a, b in zip(A, B)])
+    cts = keys.encrypt_bits(bits.reshape(-1)).reshape(reps, 16, params.n + 1)
+    run = CircuitRunner(engine, net, reps)
+    run.set_inputs(cts)
+    out = run.run().outputs()
+    dec = np.array(keys.decrypt_bits(out.reshape(-1, params.n + 1))).reshape(reps, 9)
+    got = (dec * (1 << np.arange(9))).sum(axis=1)
+    assert np.array_equal(got, A + B)
+    # replica 0, gate by gate, bit-exact against the oracle walking the same netlist
+    pl = orc.Plan(params.N)
+    w = [None, None] + list(cts[0])
+    triv = np.zeros((2, params.n + 1), np.uint32)
+    triv[0, -1], triv[1, -1] = 0xE0000000, 0x20000000
+    w[0], w[1] = triv[0], triv[1]
+    for op, a, b in net.gates:
+        w.append(orc.gate(params, pl, op, keys.bk_f, None, keys.ksk, w[a], w[b]))
+    for k, wi in enumerate(net.outputs):
+        assert np.array_equal(out[0, k], w[wi])
+    # mixed-gate adder (XOR/AND/OR bootstraps): same sums, fewer waves
+    net2 = ripple_carry_adder(8, nand_only=False)
+    run2 = CircuitRunner(engine, net2, reps)
+    run2.set_inputs(cts)
+    dec2 = np.array(keys.decrypt_bits(run2.run().outputs().reshape(-1, params.n + 1))).reshape(reps, 9)
+    assert np.array_equal((dec2 * (1 << np.arange(9))).sum(axis=1), A + B)
+    assert net2.describe()["depth"] < net.describe()["depth"]
+
+
+@pytest.mark.gpu
+def test_mux_via_netlist_matches_mux_batch(engine, keys, gold_gate):
+    from rustfhe_amd.circuit import CircuitRunner, Netlist
+    net = Netlist()
+    c, x, y = net.inputs(3)
+    net.output(net.mux(c, x, y))
+    run = CircuitRunner(engine, net, 1)
+    run.set_inputs(np.stack([gold_gate["in0"][2], gold_gate["in0"][0], gold_gate["in1"][1]])[None])
+    assert np.array_equal(run.run().outputs()[0, 0], gold_gate["mux_out"])
