@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gates", type=int, default=1024, help="gates per GPU per step (BASELINE configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-gates-per-thread", type=int, default=24)
+    ap.add_argument("--cpu-gates-per-thread", type=int, default=8)
     args = ap.parse_args()
 
     import torch
