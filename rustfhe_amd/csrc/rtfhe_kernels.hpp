@@ -138,30 +138,29 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
     wave_lds_sync();
 }
 
-// identity key switch of the lvl1 sample held as a'[0..N) in LDS (+ b'), one wave.
-// Rows are subtracted in a different order than the reference's (i, l) loop: wrapping u32 addition is
-// commutative and associative, so the result is bit-identical (hom_nand/src/tlwe.rs:64-72).
+// identity key switch of the lvl1 sample held as a'[0..N) in LDS (+ b'), hom_nand/src/tlwe.rs:43-73.
+// ks_accumulate sums the selected rows for coefficients [i_begin, i_end) into per-lane uint4 accumulators (lane holds
+// columns 4 (lane + 64 q) .. +3).  Rows are added in a different order than the reference's (i, l) loop: wrapping u32
+// addition is commutative and associative, so the result is bit-identical.
 template <int LOGN, int KS_T, int KS_BB, int KSQ>
-__device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ aprime, uint32_t bprime,
-                                                const uint32_t* __restrict__ ksk, int ksw, int n,
-                                                uint32_t* __restrict__ out, int lane) {
+__device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprime, int i_begin, int i_end,
+                                              const uint32_t* __restrict__ ksk, int ksw, uint4 (&sum)[KSQ], int lane) {
     constexpr int N = 1 << LOGN;
     constexpr int BASE1 = (1 << KS_BB) - 1;
     constexpr uint32_t ROUND = (32 - KS_T * KS_BB) != 0 ? (1u << (32 - KS_T * KS_BB - 1)) : 0u;
     const int zero_row = N * KS_T * BASE1;
     // lanes past the end of a row re-read its last 16 bytes (branch-free); the columns they accumulate are never stored
-    uint4 sum[KSQ];
     int idx[KSQ];
 #pragma unroll
     for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); idx[q] = min(lane + 64 * q, ksw / 4 - 1); }
 #pragma unroll 1
-    for (int i = 0; i < N; i++) {
+    for (int i = i_begin; i < i_end; i++) {
         const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(aprime[i] + ROUND));
         uint4 v[KS_T][KSQ];
 #pragma unroll
         for (int l = 0; l < KS_T; l++) {
             const uint32_t d = (u >> (32 - KS_BB * (l + 1))) & ((1u << KS_BB) - 1u);
-            const int row = d ? ((i * KS_T + l) * BASE1 + (int)d - 1) : zero_row;
+            const int row = d ? ((i * KS_T + l) * BASE1 + (int)d - 1) : zero_row;   // digit 0 -> the shared all-zero row
             const uint4* p = reinterpret_cast<const uint4*>(ksk + (size_t)row * ksw);
 #pragma unroll
             for (int q = 0; q < KSQ; q++) v[l][q] = p[idx[q]];
@@ -173,6 +172,14 @@ __device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ apr
                 sum[q].x += v[l][q].x; sum[q].y += v[l][q].y; sum[q].z += v[l][q].z; sum[q].w += v[l][q].w;
             }
     }
+}
+
+template <int LOGN, int KS_T, int KS_BB, int KSQ>
+__device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ aprime, uint32_t bprime,
+                                                const uint32_t* __restrict__ ksk, int ksw, int n,
+                                                uint32_t* __restrict__ out, int lane) {
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(aprime, 0, 1 << LOGN, ksk, ksw, sum, lane);
 #pragma unroll
     for (int q = 0; q < KSQ; q++) {
         const int col = 4 * (lane + 64 * q);

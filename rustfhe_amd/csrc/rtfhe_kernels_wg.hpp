@@ -1,0 +1,189 @@
+// rtfhe_kernels_wg.hpp -- latency-oriented variant of the bootstrap kernel: ONE GATE PER WORKGROUP.
+//
+// k_bootstrap (rtfhe_kernels.hpp) gives each gate one wavefront: best throughput once a launch has >= 4 gates per
+// CU, but a gate then takes ~8.5 ms however few gates there are.  Dependency waves of a circuit (BASELINE config 4)
+// and single hom_nand() calls are small; here the 8 waves of a 512-thread workgroup share one gate:
+//
+//   per CMUX step (same arithmetic, same operation order as the reference -- see cmux_step for citations):
+//     F  waves 0..2l-1 : wave j gathers/decomposes digit polynomial j and runs its forward transform, spectrum -> LDS
+//     -- barrier --
+//     M  all 8 waves   : wave w owns points (lane << 3) | w of both accumulator spectra and runs their MAC chains
+//                        over the 2l rows IN ROW ORDER (the reference's fold order), BK values prefetched at step start
+//     -- barrier --
+//     I  waves 0, 1    : inverse transform of component 0 / 1, truncate, += into the LDS accumulator
+//     -- barrier --
+//   key switch: each wave sums the rows of N/8 coefficients, partial sums reduced through LDS.
+//
+// Only N = 1024 (R = 8 points per lane = 8 waves for the M phase; LDS 134 KiB).
+#pragma once
+
+#include "rtfhe_kernels.hpp"
+
+namespace rtfhe {
+
+template <int LOGN, int L>
+struct WgLds {
+    typedef Geo<LOGN> G;
+    static constexpr int NW = 8;
+    static constexpr size_t TW = 0;
+    static constexpr size_t ACC = TW + (size_t)G::TW_TOTAL * sizeof(cplx);
+    static constexpr size_t SPEC = ACC + (size_t)2 * G::N * 4;                       // cplx[2l][P]  (also key-switch partials)
+    static constexpr size_t SBUF = SPEC + (size_t)2 * L * G::P * sizeof(cplx);       // cplx[2][P]
+    static constexpr size_t XBUF = SBUF + (size_t)2 * G::P * sizeof(cplx);           // double[2l][XSLOTS]
+    static constexpr size_t ABAR = XBUF + (size_t)2 * L * G::XSLOTS * sizeof(double);
+    __host__ __device__ static constexpr size_t bytes(int npad) { return ABAR + (size_t)npad * 4; }
+};
+
+template <int LOGN, int L, int BGBIT, int KS_T, int KS_BB, int KSQ>
+__global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) {
+    typedef Geo<LOGN> G;
+    typedef WgLds<LOGN, L> S;
+    constexpr int N = G::N, P = G::P, R = G::R, NW = S::NW, ROWS = 2 * L;
+    static_assert(R == NW, "the MAC phase gives each of the 8 waves one of the R = 8 points a lane holds");
+    static_assert(ROWS <= NW, "one forward transform per wave");
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem + S::TW);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(smem + S::ACC);
+    cplx* spec = reinterpret_cast<cplx*>(smem + S::SPEC);
+    cplx* sbuf = reinterpret_cast<cplx*>(smem + S::SBUF);
+    uint32_t* abar = reinterpret_cast<uint32_t*>(smem + S::ABAR);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* xbuf = reinterpret_cast<double*>(smem + S::XBUF) + (size_t)(wave < ROWS ? wave : 0) * G::XSLOTS;
+    const cplx* twf = tw;
+    const cplx* twi = tw + G::TW_DIR;
+    const int g = blockIdx.x;                       // grid = count
+    const int n = a.n;
+
+    for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * NW) tw[idx] = a.tw[idx];
+    {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108)
+        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
+        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
+        const int op = a.ops ? a.ops[g] : a.op;
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = tid; i <= n; i += 64 * NW) {
+            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
+        }
+    }
+    __syncthreads();
+    {   // acc = X^{-bbar} * testvec (tfhe.rs:85, 98-106)
+        const int bbar = (int)abar[n];
+        for (int c = tid; c < N; c += 64 * NW) {
+            const int e = (c + bbar) & (2 * N - 1);
+            accbuf[c] = (e >> LOGN) ? 0xE0000000u : 0x20000000u;
+            accbuf[N + c] = 0u;
+        }
+    }
+    __syncthreads();
+
+    const size_t trgsw_cplx = (size_t)ROWS * 2 * R * 64;
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        const cplx* bk_i = a.bk + (size_t)i * trgsw_cplx;
+        // BK values this wave needs in the M phase: point m = wave of every row and component (coalesced 1 KiB each)
+        cplx bkv[ROWS][2];
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+            bkv[j][0] = bk_i[(size_t)((j * 2 + 0) * R + wave) * 64 + lane];
+            bkv[j][1] = bk_i[(size_t)((j * 2 + 1) * R + wave) * 64 + lane];
+        }
+        // ---- F: one digit polynomial per wave (trgsw.rs:269-289) ----
+        if (wave < ROWS) {
+            const int h = wave / L, jj = wave - h * L;
+            const uint32_t* poly = accbuf + h * N;
+            double re[R], im[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const int c0 = lane + 64 * m, c1 = c0 + P;
+                const uint32_t d0 = rotated_coef<LOGN>(poly, c0, r) - poly[c0];
+                const uint32_t d1 = rotated_coef<LOGN>(poly, c1, r) - poly[c1];
+                re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
+                im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
+            }
+            fft_forward<LOGN>(re, im, twf, xbuf, lane);
+            cplx* dst = spec + (size_t)wave * P + lane;
+#pragma unroll
+            for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
+        }
+        __syncthreads();
+        // ---- M: hadamard + fold-add from zero in row order (spqlios.rs:204-222, trgsw.rs:290-299), point m = wave ----
+        {
+            double s0r = 0.0, s0i = 0.0, s1r = 0.0, s1i = 0.0;
+            const cplx* src = spec + wave * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < ROWS; j++) {
+                const cplx d = src[(size_t)j * P];
+                {
+                    const double ii = bkv[j][0].y * d.y, rr = bkv[j][0].x * d.x, ri = bkv[j][0].x * d.y, ir = bkv[j][0].y * d.x;
+                    s0r = s0r + (rr - ii);
+                    s0i = s0i + (ir + ri);
+                }
+                {
+                    const double ii = bkv[j][1].y * d.y, rr = bkv[j][1].x * d.x, ri = bkv[j][1].x * d.y, ir = bkv[j][1].y * d.x;
+                    s1r = s1r + (rr - ii);
+                    s1i = s1i + (ir + ri);
+                }
+            }
+            sbuf[wave * 64 + lane] = make_double2(s0r, s0i);
+            sbuf[P + wave * 64 + lane] = make_double2(s1r, s1i);
+        }
+        __syncthreads();
+        // ---- I: one accumulator component per wave (math.rs:279-288; trlwe.rs:49-60 for the += ) ----
+        if (wave < 2) {
+            double re[R], im[R];
+            const cplx* src = sbuf + (size_t)wave * P + lane;
+#pragma unroll
+            for (int m = 0; m < R; m++) { const cplx v = src[m * 64]; re[m] = v.x; im[m] = v.y; }
+            fft_inverse<LOGN>(re, im, twi, xbuf, lane);
+            uint32_t* poly = accbuf + wave * N;
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const int c = lane + 64 * m;
+                poly[c] += trunc_to_torus(re[m]);
+                poly[c + P] += trunc_to_torus(im[m]);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        uint32_t* o = a.out + (size_t)g * 2 * N;
+        for (int c = tid; c < 2 * N; c += 64 * NW) o[c] = accbuf[c];
+        return;
+    }
+
+    // sample extract index 0 (trlwe.rs:110-121) into the now free abar/spec area is not needed: a' is written over a(X)
+    uint32_t av[N / (64 * NW)];
+#pragma unroll
+    for (int k = 0; k < N / (64 * NW); k++) av[k] = accbuf[N + tid + 64 * NW * k];
+    const uint32_t bprime = accbuf[0];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N / (64 * NW); k++) {
+        const int c = tid + 64 * NW * k;
+        accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[k] : (0u - av[k]);
+    }
+    __syncthreads();
+    // key switch: wave w sums the rows of coefficients [w N/8, (w+1) N/8); partial sums meet in LDS
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, wave * (N / NW), (wave + 1) * (N / NW), a.ksk, a.ksw, sum, lane);
+    uint4* part = reinterpret_cast<uint4*>(spec);          // [NW][KSQ][64] uint4 = 24 KiB
+#pragma unroll
+    for (int q = 0; q < KSQ; q++) part[(wave * KSQ + q) * 64 + lane] = sum[q];
+    __syncthreads();
+    uint32_t* out = a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1);
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(spec);
+    for (int col = tid; col <= n; col += 64 * NW) {
+        // column col lives in uint4 slot (col/4) = lane + 64 q, element col % 4
+        const int slot = col >> 2, q = slot >> 6, ln = slot & 63, e = col & 3;
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += pw[((w * KSQ + q) * 64 + ln) * 4 + e];
+        out[col] = ((col == n) ? bprime : 0u) - s;
+    }
+}
+
+}  // namespace rtfhe

@@ -186,3 +186,27 @@ def test_error_paths(engine, params):
         fresh.gate_batch(R.NAND, np.zeros((1, params.n + 1), np.uint32), np.zeros((1, params.n + 1), np.uint32))
     assert ei.value.code == R._ffi.ERR_STATE
     fresh.close()
+
+
+@pytest.mark.parametrize("force", ["1", "4", "8"])
+def test_all_kernel_shapes_match_golden(params, keys, gold_gate, force, monkeypatch):
+    """The three launch shapes (workgroup-per-gate, 4-wave and 8-wave wave-per-gate) are the same arithmetic:
+    each one, forced through RTFHE_FORCE_WAVES, reproduces the golden gates bit for bit."""
+    import rustfhe_amd as R
+    monkeypatch.setenv("RTFHE_FORCE_WAVES", force)
+    e = R.Engine(R.Params(), 0)
+    try:
+        e.load_bk_fft(keys.bk_f)          # also covers the FrrSeries-domain key import (reference's BootstrappingKey form)
+        e.load_ksk(keys.ksk)
+        ops, in0, in1 = gold_gate["ops"], gold_gate["in0"], gold_gate["in1"]
+        nand = [g for g in range(len(ops)) if ops[g] == R.NAND]
+        out = e.gate_batch(R.NAND, in0[nand], in1[nand])
+        assert np.array_equal(out, gold_gate["out"][nand])
+        for g in range(len(ops)):
+            if ops[g] != R.NAND:
+                assert np.array_equal(e.gate_batch(int(ops[g]), in0[g:g + 1], in1[g:g + 1])[0], gold_gate["out"][g])
+        t = np.stack([keys.encrypt_bits([0])[0]] * 3)
+        acc = e.blind_rotate_batch(t, 2)
+        assert np.array_equal(acc[0], acc[1]) and np.array_equal(acc[0], acc[2])
+    finally:
+        e.close()
