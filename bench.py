@@ -79,15 +79,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
+    # RTFHE_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("RTFHE_BENCH_BACKEND", "nccl")
+    dev = local if backend == "nccl" else local % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     params = R.Params()
     key0, key1, bk, ksk = R.keygen(params, 20211003)           # same key set on every rank (replicated keys)
-    eng = R.Engine(params, local)
+    eng = R.Engine(params, dev)
     eng.load_bk_torus(bk)
     eng.load_ksk(ksk)
 
@@ -119,7 +125,7 @@ def main():
 
     out = d_out.cpu().numpy().view(np.uint32)
     ok = bool(np.array_equal(R.decrypt_bits(params, key0, out), 1 - (b0 & b1)))
-    t = torch.tensor([elapsed, 0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, 0.0 if ok else 1.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, bad = float(t[0]), float(t[1])
