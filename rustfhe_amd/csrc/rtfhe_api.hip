@@ -244,7 +244,7 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         if (force == 8 || (force == 0 && a.count > 4 * ctx->num_cus)) return launch_bootstrap_w<10, 8>(ctx, a, s);
         return launch_bootstrap_w<10, 4>(ctx, a, s);
     } else {
-        return launch_bootstrap_w<11, 2>(ctx, a, s);
+        return launch_bootstrap_w<11, 4>(ctx, a, s);   // inverse pass-1/untwist twiddles stay in global memory: 4 gates per CU fit
     }
 }
 
@@ -290,7 +290,7 @@ int launch_fft(rtfhe_ctx* ctx, bool forward, FftArgs a, hipStream_t s) {
 
 template <int LOGN>
 int launch_extprod_t(rtfhe_ctx* ctx, ExtProdArgs a, hipStream_t s) {
-    constexpr int W = (LOGN == 10) ? 4 : 2;
+    constexpr int W = 4;
     auto k = k_external_product<LOGN, 3, 6, W>;
     const size_t lds = bootstrap_lds_bytes<LOGN>(W, 0);
     if (int rc = allow_lds(ctx, k, lds)) return rc;

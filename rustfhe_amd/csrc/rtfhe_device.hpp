@@ -263,23 +263,47 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 
 // Inverse transform.  in: layout L3, unscaled (the 2/N factor lives in the untwist twiddles).  out: layout L1, untwisted (natural
 // coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
+// tw_small holds the pass-2/3 entries (always LDS), tw_big the pass-1 and untwist entries (LDS, or -- where the LDS
+// budget is better spent on resident gates, N = 2048 -- the global table; both pointers use the per-direction offsets).
 template <int LOGN>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                            const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+                                            const cplx* __restrict__ tw_small, const cplx* __restrict__ tw_big,
+                                            double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
     Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1; Tw<R> wt;
-    w3.load(tw + G::TW_P3, 1);
+    w3.load(tw_small + G::TW_P3, 1);
     P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
-    w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+    w2.load(tw_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
     exchange<LOGN, 3, 2>(re, im, xbuf, lane);
     P12<R, G::LR - 1>::inv(re, im, w2.w);
-    w1.load(tw + G::TW_P1 + lane, 64);
+    w1.load(tw_big + G::TW_P1 + lane, 64);          // in flight during the exchange
     exchange<LOGN, 2, 1>(re, im, xbuf, lane);
-    wt.load(tw + G::TW_TWIST + lane, 64);
+    wt.load(tw_big + G::TW_TWIST + lane, 64);
     P12<R, G::LR - 1>::inv(re, im, w1.w);
     twist_mul<R>(re, im, wt.w);
 }
+
+// Twiddle staging: the forward table and the inverse table's small part always live in LDS; the inverse table's
+// big part (untwist + pass 1) stays in global memory when SPLIT (N = 2048: 31 KiB of LDS = one more resident gate).
+template <int LOGN>
+struct TwStage {
+    typedef Geo<LOGN> G;
+    static constexpr bool SPLIT = (LOGN >= 11);
+    static constexpr int LDS_CPLX = SPLIT ? G::TW_DIR + (G::TW_DIR - G::TW_P2) : G::TW_TOTAL;
+    // copies into `lds` (caller barriers afterwards)
+    __device__ __forceinline__ static void stage(cplx* __restrict__ lds, const cplx* __restrict__ global, int tid, int nthreads) {
+        if constexpr (SPLIT) {
+            for (int idx = tid; idx < G::TW_DIR; idx += nthreads) lds[idx] = global[idx];
+            for (int idx = tid + G::TW_P2; idx < G::TW_DIR; idx += nthreads) lds[G::TW_DIR + idx - G::TW_P2] = global[G::TW_DIR + idx];
+        } else {
+            for (int idx = tid; idx < G::TW_TOTAL; idx += nthreads) lds[idx] = global[idx];
+        }
+    }
+    __device__ __forceinline__ static const cplx* fwd(const cplx* lds) { return lds; }
+    __device__ __forceinline__ static const cplx* inv_small(const cplx* lds) { return SPLIT ? lds + G::TW_DIR - G::TW_P2 : lds + G::TW_DIR; }
+    __device__ __forceinline__ static const cplx* inv_big(const cplx* lds, const cplx* global) { return SPLIT ? global + G::TW_DIR : lds + G::TW_DIR; }
+};
 
 // Torus32(int64_t(x)): truncate toward zero, keep the low 32 bits (fft_processor_spqlios.cpp:182).
 // trunc(x) + 1.5*2^52 is exact for |x| < 2^51 (the path's values stay below 2^50: 2l*N*(Bg/2)*2^31),

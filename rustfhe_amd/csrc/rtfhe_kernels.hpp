@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1
 // accbuf: LDS u32 [2][N] (b then a).  bk_i: this TRGSW in device layout [2l][2][R][64] cplx.
 template <int LOGN, int L, int BGBIT, bool CMUX>
 __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, const cplx* __restrict__ bk_i,
-                                          const cplx* __restrict__ twf, const cplx* __restrict__ twi,
+                                          const cplx* __restrict__ twf, const cplx* __restrict__ twi, const cplx* __restrict__ twi_big,
                                           double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
     constexpr int N = G::N, P = G::P, R = G::R;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
             re[m] = comp ? s1re[m] : s0re[m];
             im[m] = comp ? s1im[m] : s0im[m];
         }
-        fft_inverse<LOGN>(re, im, twi, xbuf, lane);
+        fft_inverse<LOGN>(re, im, twi, twi_big, xbuf, lane);
         uint32_t* poly = accbuf + comp * N;
 #pragma unroll
         for (int m = 0; m < R; m++) {
@@ -196,7 +196,7 @@ __host__ __device__ constexpr size_t bootstrap_wave_lds_bytes(int npad) {
 }
 template <int LOGN>
 __host__ __device__ constexpr size_t bootstrap_lds_bytes(int waves, int npad) {
-    return (size_t)Geo<LOGN>::TW_TOTAL * sizeof(cplx) + (size_t)waves * bootstrap_wave_lds_bytes<LOGN>(npad);
+    return (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)waves * bootstrap_wave_lds_bytes<LOGN>(npad);
 }
 
 // The hot-path kernel: pre-step, blind rotate (n CMUX steps), sample extract and identity key switch
@@ -206,21 +206,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
     typedef Geo<LOGN> G;
     constexpr int N = G::N, R = G::R;
     extern __shared__ __align__(16) unsigned char smem[];
-    cplx* tw = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * WAVES) tw[idx] = a.tw[idx];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    TwStage<LOGN>::stage(tw, a.tw, tid, 64 * WAVES);
     __syncthreads();
     // from here on waves never synchronise with each other
 
     const int g = blockIdx.x * WAVES + wave;
     if (g >= a.count) return;
 
-    unsigned char* wbase = smem + (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(a.npad);
+    unsigned char* wbase = smem + (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(a.npad);
     double* xbuf = reinterpret_cast<double*>(wbase);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(double));
     uint32_t* abar = accbuf + 2 * N;
-    const cplx* twf = tw;
-    const cplx* twi = tw + G::TW_DIR;
+    const cplx* twf = TwStage<LOGN>::fwd(tw);
+    const cplx* twi = TwStage<LOGN>::inv_small(tw);
+    const cplx* twi_big = TwStage<LOGN>::inv_big(tw, a.tw);
 
     const int n = a.n;
     // pre-step + mod switch (tfhe.rs:97, 107-108): b floor, a_i rounded, both to [0, 2N)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        cmux_step<LOGN, L, BGBIT, true>(accbuf, r, a.bk + (size_t)i * trgsw_cplx, twf, twi, xbuf, lane);
+        cmux_step<LOGN, L, BGBIT, true>(accbuf, r, a.bk + (size_t)i * trgsw_cplx, twf, twi, twi_big, xbuf, lane);
     }
 
     if (a.mode == MODE_BLIND_ROTATE) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_inverse(const FftArgs a) 
         double re[R], im[R];   // 2/N is folded into the untwist twiddles
 #pragma unroll
         for (int m = 0; m < R; m++) { re[m] = src[G::pos3(lane, m)]; im[m] = src[P + G::pos3(lane, m)]; }
-        fft_inverse<LOGN>(re, im, tw, xbuf, lane);
+        fft_inverse<LOGN>(re, im, tw, tw, xbuf, lane);
         uint32_t* dst = reinterpret_cast<uint32_t*>(a.dst) + (size_t)g * N;
 #pragma unroll
         for (int m = 0; m < R; m++) { dst[lane + 64 * m] = trunc_to_torus(re[m]); dst[lane + 64 * m + P] = trunc_to_torus(im[m]); }
@@ -385,19 +386,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_external_product(const ExtPro
     typedef Geo<LOGN> G;
     constexpr int N = G::N, R = G::R;
     extern __shared__ __align__(16) unsigned char smem[];
-    cplx* tw = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * WAVES) tw[idx] = a.tw[idx];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    TwStage<LOGN>::stage(tw, a.tw, tid, 64 * WAVES);
     __syncthreads();
     const int g = blockIdx.x * WAVES + wave;
     if (g >= a.count) return;
-    unsigned char* wbase = smem + (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(0);
+    unsigned char* wbase = smem + (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(0);
     double* xbuf = reinterpret_cast<double*>(wbase);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(double));
     for (int c = lane; c < 2 * N; c += 64) accbuf[c] = a.trlwe[(size_t)g * 2 * N + c];
     wave_lds_sync();
     const size_t trgsw_cplx = (size_t)2 * L * 2 * R * 64;
-    cmux_step<LOGN, L, BGBIT, false>(accbuf, 0, a.bk + (size_t)a.bk_index[g] * trgsw_cplx, tw, tw + G::TW_DIR, xbuf, lane);
+    cmux_step<LOGN, L, BGBIT, false>(accbuf, 0, a.bk + (size_t)a.bk_index[g] * trgsw_cplx, TwStage<LOGN>::fwd(tw), TwStage<LOGN>::inv_small(tw), TwStage<LOGN>::inv_big(tw, a.tw), xbuf, lane);
     for (int c = lane; c < 2 * N; c += 64) a.out[(size_t)g * 2 * N + c] = accbuf[c];
 }
 

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             const cplx* src = sbuf + (size_t)wave * P + lane;
 #pragma unroll
             for (int m = 0; m < R; m++) { const cplx v = src[m * 64]; re[m] = v.x; im[m] = v.y; }
-            fft_inverse<LOGN>(re, im, twi, xbuf, lane);
+            fft_inverse<LOGN>(re, im, twi, twi, xbuf, lane);
             uint32_t* poly = accbuf + wave * N;
 #pragma unroll
             for (int m = 0; m < R; m++) {
