@@ -153,24 +153,31 @@ __device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprim
     int idx[KSQ];
 #pragma unroll
     for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); idx[q] = min(lane + 64 * q, ksw / 4 - 1); }
+    // KS_UI coefficients per iteration: KS_UI * KS_T rows (3 x 16 B per lane each) in flight per wave
+    constexpr int KS_UI = 2;
 #pragma unroll 1
-    for (int i = i_begin; i < i_end; i++) {
-        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(aprime[i] + ROUND));
-        uint4 v[KS_T][KSQ];
+    for (int i = i_begin; i < i_end; i += KS_UI) {
+        uint4 v[KS_UI][KS_T][KSQ];
 #pragma unroll
-        for (int l = 0; l < KS_T; l++) {
-            const uint32_t d = (u >> (32 - KS_BB * (l + 1))) & ((1u << KS_BB) - 1u);
-            const int row = d ? ((i * KS_T + l) * BASE1 + (int)d - 1) : zero_row;   // digit 0 -> the shared all-zero row
-            const uint4* p = reinterpret_cast<const uint4*>(ksk + (size_t)row * ksw);
+        for (int k = 0; k < KS_UI; k++) {
+            const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(aprime[i + k] + ROUND));
 #pragma unroll
-            for (int q = 0; q < KSQ; q++) v[l][q] = p[idx[q]];
+            for (int l = 0; l < KS_T; l++) {
+                const uint32_t d = (u >> (32 - KS_BB * (l + 1))) & ((1u << KS_BB) - 1u);
+                const int row = d ? (((i + k) * KS_T + l) * BASE1 + (int)d - 1) : zero_row;   // digit 0 -> the shared all-zero row
+                const uint4* p = reinterpret_cast<const uint4*>(ksk + (size_t)row * ksw);
+#pragma unroll
+                for (int q = 0; q < KSQ; q++) v[k][l][q] = p[idx[q]];
+            }
         }
 #pragma unroll
-        for (int l = 0; l < KS_T; l++)
+        for (int k = 0; k < KS_UI; k++)
 #pragma unroll
-            for (int q = 0; q < KSQ; q++) {
-                sum[q].x += v[l][q].x; sum[q].y += v[l][q].y; sum[q].z += v[l][q].z; sum[q].w += v[l][q].w;
-            }
+            for (int l = 0; l < KS_T; l++)
+#pragma unroll
+                for (int q = 0; q < KSQ; q++) {
+                    sum[q].x += v[k][l][q].x; sum[q].y += v[k][l][q].y; sum[q].z += v[k][l][q].z; sum[q].w += v[k][l][q].w;
+                }
     }
 }
 
