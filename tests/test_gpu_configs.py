@@ -81,3 +81,43 @@ def test_config5_gates_n2048(setup2048, orc):
     pick = rng.choice(1024, 48, replace=False)
     exp, _ = orc.gate_batch_mt(P, orc.NAND, K.bk_f, None, K.ksk, d0[pick], d1[pick], nthreads=min(32, os.cpu_count() or 1))
     assert np.array_equal(out[pick], exp)
+
+
+@pytest.mark.parametrize("n", [1, 60, 767])
+def test_other_tlwe_dimensions(orc, n):
+    """n is a runtime parameter of the engine (1 <= n <= 767); the reference exercises small dimensions in its
+    key-switch test (hom_nand/src/tlwe.rs:346-396: 256 -> 60).  Bit-exact against the oracle for each."""
+    import rustfhe_amd as R
+    P = orc.Params(n=n)
+    K = orc.Keys(P, 1000 + n)
+    e = R.Engine(R.Params(n=n), 0)
+    try:
+        e.load_bk_torus(K.bk_t)
+        e.load_ksk(K.ksk)
+        pl = orc.Plan(P.N)
+        b0, b1 = [0, 1, 1, 0, 1], [1, 1, 0, 0, 1]
+        c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
+        for op in (R.NAND, R.OR):
+            out = e.gate_batch(op, c0, c1)
+            exp = np.stack([orc.gate(P, pl, op, K.bk_f, None, K.ksk, x, y) for x, y in zip(c0, c1)])
+            assert np.array_equal(out, exp)
+        if n >= 60:     # enough key entropy for the noise budget to hold
+            assert K.decrypt_bits(e.gate_batch(R.NAND, c0, c1)) == [1, 0, 1, 1, 0]
+    finally:
+        e.close()
+
+
+def test_degenerate_inputs(engine, orc, params, keys):
+    """All-zero and all-ones words: every mod-switched rotation is 0 (no-op CMUX: cross(0) = 0 exactly) or 2N-1."""
+    import rustfhe_amd as R
+    pl = orc.Plan(params.N)
+    z = np.zeros((1, params.n + 1), np.uint32)
+    f = np.full((1, params.n + 1), 0xFFFFFFFF, np.uint32)
+    half = np.full((1, params.n + 1), 0x80000000, np.uint32)
+    for a, b, op in ((z, z, R.NAND), (z, z, R.COPY), (f, f, R.AND), (half, z, R.XOR), (f, z, R.NOT)):
+        out = e_out = engine.gate_batch(op, a, b)
+        exp = orc.gate(params, pl, op, keys.bk_f, None, keys.ksk, a[0], b[0])
+        assert np.array_equal(e_out[0], exp)
+    # a bootstrap of a pre-combined TLWE equals the COPY gate
+    t = keys.encrypt_bits([1])
+    assert np.array_equal(engine.bootstrap_batch(t), engine.gate_batch(R.COPY, t))
