@@ -167,6 +167,7 @@ struct rtfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
+    unsigned long long* d_dbg = nullptr;   // RTFHE_WG_STAMPS builds: 64 words of phase timings
     int num_cus = 256;
     int force_waves = 0;   // RTFHE_FORCE_WAVES=1|4|8 (tuning knob: 1 = workgroup-per-gate kernel)
     int wg_max = 512;      // RTFHE_WG_MAX_GATES: largest batch routed to the workgroup-per-gate kernel
@@ -261,6 +262,7 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.count = (int)count; a.op = op; a.n = ctx->p.n; a.steps = steps; a.mode = mode; a.ksw = ctx->ksw;
     a.npad = (ctx->p.n + 1 + 63) / 64 * 64;
     a.ops = d_ops; a.idx0 = d_idx0; a.idx1 = d_idx1; a.idx_out = d_idx_out;
+    a.dbg = ctx->d_dbg;
     return ctx->logn == 10 ? launch_bootstrap_t<10>(ctx, a, s) : launch_bootstrap_t<11>(ctx, a, s);
 }
 
@@ -377,9 +379,19 @@ int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
     if (!rc && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess))
         rc = fail(ctx, RTFHE_ERR_HIP, "hipEventCreate failed");
     if (rc) { g_last_error = ctx->err; rtfhe_ctx_destroy(ctx); return rc; }
+#ifdef RTFHE_WG_STAMPS
+    if (hipMalloc((void**)&ctx->d_dbg, 64 * 8) == hipSuccess) (void)hipMemset(ctx->d_dbg, 0, 64 * 8);
+#endif
     *out = ctx;
     return 0;
 }
+
+#ifdef RTFHE_WG_STAMPS
+extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out64) {
+    if (!ctx || !ctx->d_dbg) return RTFHE_ERR_STATE;
+    return hipMemcpy(out64, ctx->d_dbg, 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : RTFHE_ERR_HIP;
+}
+#endif
 
 void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (!ctx) return;

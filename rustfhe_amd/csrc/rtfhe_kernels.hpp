@@ -37,6 +37,7 @@ struct BootstrapArgs {
     const int32_t* idx0;
     const int32_t* idx1;
     const int32_t* idx_out;
+    unsigned long long* dbg;   // diagnostic builds only (RTFHE_WG_STAMPS): per-phase cycle sums of workgroup 0
 };
 
 // gate pre-step on one TLWE word (a-part: isb = false, b-part: isb = true), hom_nand/src/tfhe.rs:27-71

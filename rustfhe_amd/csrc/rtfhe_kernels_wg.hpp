@@ -78,6 +78,12 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     }
     __syncthreads();
 
+#ifdef RTFHE_WG_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define WG_STAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
     const size_t trgsw_cplx = (size_t)ROWS * 2 * R * 64;
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             bkv[j][0] = bk_i[(size_t)((j * 2 + 0) * R + wave) * 64 + lane];
             bkv[j][1] = bk_i[(size_t)((j * 2 + 1) * R + wave) * 64 + lane];
         }
+        WG_STAMP(0);
         // ---- F: one digit polynomial per wave (trgsw.rs:269-289) ----
         if (wave < ROWS) {
             const int h = wave / L, jj = wave - h * L;
@@ -108,7 +115,9 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
 #pragma unroll
             for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
         }
+        WG_STAMP(1);
         __syncthreads();
+        WG_STAMP(2);
         // ---- M: hadamard + fold-add from zero in row order (spqlios.rs:204-222, trgsw.rs:290-299), point m = wave ----
         {
             double s0r = 0.0, s0i = 0.0, s1r = 0.0, s1i = 0.0;
@@ -130,7 +139,9 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             sbuf[wave * 64 + lane] = make_double2(s0r, s0i);
             sbuf[P + wave * 64 + lane] = make_double2(s1r, s1i);
         }
+        WG_STAMP(3);
         __syncthreads();
+        WG_STAMP(4);
         // ---- I: one accumulator component per wave (math.rs:279-288; trlwe.rs:49-60 for the += ) ----
         if (wave < 2) {
             double re[R], im[R];
@@ -146,8 +157,14 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                 poly[c + P] += trunc_to_torus(im[m]);
             }
         }
+        WG_STAMP(5);
         __syncthreads();
+        WG_STAMP(6);
     }
+#ifdef RTFHE_WG_STAMPS
+    if (a.dbg && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];
+#endif
 
     if (a.mode == MODE_BLIND_ROTATE) {
         uint32_t* o = a.out + (size_t)g * 2 * N;
