@@ -214,7 +214,7 @@ int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
 template <int LOGN, int W>
 int launch_bootstrap_w(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     auto k = k_bootstrap<LOGN, 3, 6, 8, 2, KSQ, W>;
-    const size_t lds = bootstrap_lds_bytes<LOGN>(W, a.npad);
+    const size_t lds = bootstrap_lds_bytes<LOGN>(W, a.npad, bootstrap_dual_xbuf(LOGN, W));
     if (int rc = allow_lds(ctx, k, lds)) return rc;
     const int grid = (a.count + W - 1) / W;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, s, a);

@@ -203,7 +203,10 @@ struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uni
 // buffer of Geo::XSLOTS doubles: slot maps FROM (written layout) and TO (read layout).  Real and imaginary
 // halves go through the same buffer one after the other (half the LDS footprint of a cplx buffer at the same
 // LDS cycle count: ds_write_b64 / ds_read_b64 move 8 B per lane per 6 / 2 cycles vs 16 B per 13 / 4).
-template <int LOGN, int FROM, int TO>
+// DUAL = true gives the real and the imaginary halves a buffer each (2 x XSLOTS doubles): both are written first and
+// then read back pair by pair in the order the next pass consumes them, so that its first butterflies start while
+// the later reads are still in flight (matters when one wave has the SIMD to itself).
+template <int LOGN, int FROM, int TO, bool DUAL = false>
 __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                          double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
@@ -213,25 +216,41 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
         const int pos = layout == 1 ? G::pos1(lane, m) : layout == 2 ? G::pos2(lane, m) : G::pos3(lane, m);
         return (FROM + TO == 3) ? G::f1(pos) : G::f2(pos);
     };
+    if constexpr (DUAL) {
+        double* xim = xbuf + G::XSLOTS;
 #pragma unroll
-    for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
-    wave_lds_sync();
+        for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
 #pragma unroll
-    for (int m = 0; m < R; m++) re[m] = xbuf[slot(TO, m)];
-    wave_lds_sync();
+        for (int m = 0; m < R; m++) xim[slot(FROM, m)] = im[m];
+        wave_lds_sync();
+        // first stage of the next pass pairs m with m + R/2
 #pragma unroll
-    for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = im[m];
-    wave_lds_sync();
+        for (int m = 0; m < R / 2; m++) {
+            re[m] = xbuf[slot(TO, m)]; re[m + R / 2] = xbuf[slot(TO, m + R / 2)];
+            im[m] = xim[slot(TO, m)];  im[m + R / 2] = xim[slot(TO, m + R / 2)];
+        }
+        wave_lds_sync();
+    } else {
 #pragma unroll
-    for (int m = 0; m < R; m++) im[m] = xbuf[slot(TO, m)];
-    wave_lds_sync();
+        for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < R; m++) re[m] = xbuf[slot(TO, m)];
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = im[m];
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < R; m++) im[m] = xbuf[slot(TO, m)];
+        wave_lds_sync();
+    }
 }
 
 // Forward transform in two parts so that a caller can issue global loads between them.
 // part A: twist, pass 1, exchange, pass 2.  in: layout L1 (re[m], im[m] = point lane + 64 m), not yet twisted.
 // part B: exchange, pass 3.                  out: layout L3 (point (lane << LR) | m) = the reference's FrrSeries order.
 // tw: LDS, forward table.  xbuf: LDS, wave-private, Geo::XSLOTS doubles.
-template <int LOGN>
+template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                               const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
@@ -242,16 +261,16 @@ __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double
     twist_mul<R>(re, im, wt.w);
     P12<R, G::LR - 1>::fwd(re, im, w1.w);
     w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);     // in flight during the exchange
-    exchange<LOGN, 1, 2>(re, im, xbuf, lane);
+    exchange<LOGN, 1, 2, DUAL>(re, im, xbuf, lane);
     P12<R, G::LR - 1>::fwd(re, im, w2.w);
 }
-template <int LOGN>
+template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                               const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     typedef Geo<LOGN> G;
     Tw<G::NLOW - 4> w3;
     w3.load(tw + G::TW_P3, 1);
-    exchange<LOGN, 2, 3>(re, im, xbuf, lane);
+    exchange<LOGN, 2, 3, DUAL>(re, im, xbuf, lane);
     P3<G::R, G::NLOW, G::LOW - 1>::fwd(re, im, w3.w);
 }
 template <int LOGN>
@@ -265,7 +284,7 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 // coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
 // tw_small holds the pass-2/3 entries (always LDS), tw_big the pass-1 and untwist entries (LDS, or -- where the LDS
 // budget is better spent on resident gates, N = 2048 -- the global table; both pointers use the per-direction offsets).
-template <int LOGN>
+template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                             const cplx* __restrict__ tw_small, const cplx* __restrict__ tw_big,
                                             double* __restrict__ xbuf, int lane) {
@@ -275,10 +294,10 @@ __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (
     w3.load(tw_small + G::TW_P3, 1);
     P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
     w2.load(tw_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
-    exchange<LOGN, 3, 2>(re, im, xbuf, lane);
+    exchange<LOGN, 3, 2, DUAL>(re, im, xbuf, lane);
     P12<R, G::LR - 1>::inv(re, im, w2.w);
     w1.load(tw_big + G::TW_P1 + lane, 64);          // in flight during the exchange
-    exchange<LOGN, 2, 1>(re, im, xbuf, lane);
+    exchange<LOGN, 2, 1, DUAL>(re, im, xbuf, lane);
     wt.load(tw_big + G::TW_TWIST + lane, 64);
     P12<R, G::LR - 1>::inv(re, im, w1.w);
     twist_mul<R>(re, im, wt.w);

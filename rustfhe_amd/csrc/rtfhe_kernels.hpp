@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1
 //   CMUX = true : acc <- cross(bk_i, X^r * acc - acc) + acc      (trgsw.rs:319-321, tfhe.rs:103-110)
 //   CMUX = false: acc <- cross(bk_i, acc)                          (trgsw.rs:264-306)
 // accbuf: LDS u32 [2][N] (b then a).  bk_i: this TRGSW in device layout [2l][2][R][64] cplx.
-template <int LOGN, int L, int BGBIT, bool CMUX>
+template <int LOGN, int L, int BGBIT, bool CMUX, bool DUAL = false>
 __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, const cplx* __restrict__ bk_i,
                                           const cplx* __restrict__ twf, const cplx* __restrict__ twi, const cplx* __restrict__ twi_big,
                                           double* __restrict__ xbuf, int lane) {
@@ -91,7 +91,7 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
                 re[m] = (double)decomp_digit(u[m], BGBIT, jj);
                 im[m] = (double)decomp_digit(u[R + m], BGBIT, jj);
             }
-            fft_forward_a<LOGN>(re, im, twf, xbuf, lane);
+            fft_forward_a<LOGN, DUAL>(re, im, twf, xbuf, lane);
             // the two BK rows of this digit are requested here, not earlier: their 64 VGPRs would otherwise be
             // live through the whole transform; the last exchange + in-register pass cover the L2 latency
             __builtin_amdgcn_sched_barrier(0);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
 #pragma unroll
             for (int m = 0; m < R; m++) { b0[m] = bkj[m * 64]; b1[m] = bkj[(R + m) * 64]; }
             __builtin_amdgcn_sched_barrier(0);
-            fft_forward_b<LOGN>(re, im, twf, xbuf, lane);
+            fft_forward_b<LOGN, DUAL>(re, im, twf, xbuf, lane);
             // hadamard + fold-add from zero, utils/src/spqlios.rs:204-222, hom_nand/src/trgsw.rs:290-299
 #pragma unroll
             for (int m = 0; m < R; m++) {
@@ -126,7 +126,7 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
             re[m] = comp ? s1re[m] : s0re[m];
             im[m] = comp ? s1im[m] : s0im[m];
         }
-        fft_inverse<LOGN>(re, im, twi, twi_big, xbuf, lane);
+        fft_inverse<LOGN, DUAL>(re, im, twi, twi_big, xbuf, lane);
         uint32_t* poly = accbuf + comp * N;
 #pragma unroll
         for (int m = 0; m < R; m++) {
@@ -198,13 +198,19 @@ __device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ apr
     }
 }
 
+// one wave per SIMD (<= 4 waves per workgroup, N = 1024): separate real/imaginary exchange buffers (see exchange<>)
+#ifdef RTFHE_NO_DUAL   // A/B builds only
+__host__ __device__ constexpr bool bootstrap_dual_xbuf(int, int) { return false; }
+#else
+__host__ __device__ constexpr bool bootstrap_dual_xbuf(int logn, int waves) { return logn == 10 && waves <= 4; }
+#endif
 template <int LOGN>
-__host__ __device__ constexpr size_t bootstrap_wave_lds_bytes(int npad) {
-    return (size_t)Geo<LOGN>::XSLOTS * sizeof(double) + (size_t)2 * Geo<LOGN>::N * 4 + (size_t)npad * 4;
+__host__ __device__ constexpr size_t bootstrap_wave_lds_bytes(int npad, bool dual = false) {
+    return (size_t)Geo<LOGN>::XSLOTS * sizeof(double) * (dual ? 2 : 1) + (size_t)2 * Geo<LOGN>::N * 4 + (size_t)npad * 4;
 }
 template <int LOGN>
-__host__ __device__ constexpr size_t bootstrap_lds_bytes(int waves, int npad) {
-    return (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)waves * bootstrap_wave_lds_bytes<LOGN>(npad);
+__host__ __device__ constexpr size_t bootstrap_lds_bytes(int waves, int npad, bool dual = false) {
+    return (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)waves * bootstrap_wave_lds_bytes<LOGN>(npad, dual);
 }
 
 // The hot-path kernel: pre-step, blind rotate (n CMUX steps), sample extract and identity key switch
@@ -223,9 +229,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
     const int g = blockIdx.x * WAVES + wave;
     if (g >= a.count) return;
 
-    unsigned char* wbase = smem + (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(a.npad);
+    constexpr bool DUAL = bootstrap_dual_xbuf(LOGN, WAVES);
+    unsigned char* wbase = smem + (size_t)TwStage<LOGN>::LDS_CPLX * sizeof(cplx) + (size_t)wave * bootstrap_wave_lds_bytes<LOGN>(a.npad, DUAL);
     double* xbuf = reinterpret_cast<double*>(wbase);
-    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(double));
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)G::XSLOTS * sizeof(double) * (DUAL ? 2 : 1));
     uint32_t* abar = accbuf + 2 * N;
     const cplx* twf = TwStage<LOGN>::fwd(tw);
     const cplx* twi = TwStage<LOGN>::inv_small(tw);
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        cmux_step<LOGN, L, BGBIT, true>(accbuf, r, a.bk + (size_t)i * trgsw_cplx, twf, twi, twi_big, xbuf, lane);
+        cmux_step<LOGN, L, BGBIT, true, DUAL>(accbuf, r, a.bk + (size_t)i * trgsw_cplx, twf, twi, twi_big, xbuf, lane);
     }
 
     if (a.mode == MODE_BLIND_ROTATE) {
