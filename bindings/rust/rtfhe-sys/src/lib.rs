@@ -1,0 +1,71 @@
+//! Raw bindings; one declaration per entry point of `include/rtfhe.h` (same order).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct rtfhe_params {
+    pub n: i32,          // TLWE lvl0 dimension    hom_nand/src/tlwe.rs:175
+    pub N: i32,          // TRLWE degree           hom_nand/src/trlwe.rs:76
+    pub nbit: i32,       // log2(N)                hom_nand/src/tfhe.rs:16
+    pub l: i32,          // gadget levels          hom_nand/src/trgsw.rs:115
+    pub bgbit: i32,      // gadget base bits       hom_nand/src/trgsw.rs:112
+    pub ks_t: i32,       // key-switch levels      hom_nand/src/tlwe.rs:178
+    pub ks_basebit: i32, // key-switch base bits   hom_nand/src/tlwe.rs:179
+}
+pub enum rtfhe_ctx {}
+
+pub const RTFHE_NAND: c_int = 0;
+pub const RTFHE_AND: c_int = 1;
+pub const RTFHE_OR: c_int = 2;
+pub const RTFHE_XOR: c_int = 3;
+pub const RTFHE_NOT: c_int = 4;
+pub const RTFHE_COPY: c_int = 5;
+pub const RTFHE_ANDNY: c_int = 6;
+
+pub const RTFHE_OK: c_int = 0;
+pub const RTFHE_ERR_INVALID: c_int = -1;
+pub const RTFHE_ERR_NO_DEVICE: c_int = -2;
+pub const RTFHE_ERR_HIP: c_int = -3;
+pub const RTFHE_ERR_STATE: c_int = -4;
+pub const RTFHE_ERR_NOMEM: c_int = -5;
+
+extern "C" {
+    pub fn rtfhe_default_params(p: *mut rtfhe_params);
+    pub fn rtfhe_ctx_create(p: *const rtfhe_params, device_id: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
+    pub fn rtfhe_ctx_destroy(ctx: *mut rtfhe_ctx);
+    pub fn rtfhe_last_error(ctx: *const rtfhe_ctx) -> *const c_char;
+    pub fn rtfhe_version() -> *const c_char;
+    pub fn rtfhe_device_count() -> c_int;
+    pub fn rtfhe_get_twiddles(ctx: *const rtfhe_ctx, ifft_table: *mut f64, fft_table: *mut f64) -> c_int;
+    pub fn rtfhe_set_twiddles(ctx: *mut rtfhe_ctx, ifft_table: *const f64, fft_table: *const f64) -> c_int;
+
+    pub fn rtfhe_load_bk_torus(ctx: *mut rtfhe_ctx, bk: *const u32) -> c_int;
+    pub fn rtfhe_load_bk_fft(ctx: *mut rtfhe_ctx, bk_f: *const f64) -> c_int;
+    pub fn rtfhe_export_bk_fft(ctx: *mut rtfhe_ctx, bk_f: *mut f64) -> c_int;
+    pub fn rtfhe_load_ksk(ctx: *mut rtfhe_ctx, ksk: *const u32) -> c_int;
+
+    pub fn rtfhe_gate_batch(ctx: *mut rtfhe_ctx, op: c_int, in0: *const u32, in1: *const u32, out: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_mux_batch(ctx: *mut rtfhe_ctx, c: *const u32, in0: *const u32, in1: *const u32, out: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_bootstrap_batch(ctx: *mut rtfhe_ctx, tlwe: *const u32, out: *mut u32, count: usize) -> c_int;
+
+    pub fn rtfhe_gate_batch_dev(ctx: *mut rtfhe_ctx, op: c_int, d_in0: *const c_void, d_in1: *const c_void, d_out: *mut c_void,
+                                count: usize, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_circuit_wave_dev(ctx: *mut rtfhe_ctx, d_ops: *const c_void, d_idx0: *const c_void, d_idx1: *const c_void,
+                                  d_idx_out: *const c_void, d_wires: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_sync(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_timer_begin(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_timer_end(ctx: *mut rtfhe_ctx, stream: *mut c_void, ms: *mut f64, launches: *mut i64) -> c_int;
+
+    pub fn rtfhe_blind_rotate_batch(ctx: *mut rtfhe_ctx, tlwe: *const u32, steps: i32, acc: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_external_product_batch(ctx: *mut rtfhe_ctx, bk_index: *const i32, trlwe: *const u32, out: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_key_switch_batch(ctx: *mut rtfhe_ctx, tlwe1: *const u32, out: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_ifft_i32_batch(ctx: *mut rtfhe_ctx, src: *const i32, res: *mut f64, count: usize) -> c_int;
+    pub fn rtfhe_fft_u32_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut u32, count: usize) -> c_int;
+
+    pub fn rtfhe_keygen(p: *const rtfhe_params, seed: u64, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_keygen_with_keys(p: *const rtfhe_params, seed: u64, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_tlwe_encrypt_bits(p: *const rtfhe_params, key0: *const i32, seed: u64, bits: *const u8, out: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_tlwe_decrypt_bits(p: *const rtfhe_params, key0: *const i32, input: *const u32, bits: *mut u8, count: usize) -> c_int;
+    pub fn rtfhe_tlwe_phase(p: *const rtfhe_params, key0: *const i32, input: *const u32, phase: *mut u32, count: usize) -> c_int;
+}
