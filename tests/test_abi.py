@@ -101,3 +101,14 @@ def test_host_bk_is_a_valid_trgsw_set(orc):
                 want = (-g * key1.astype(np.int64)) % 2 ** 32
             err = ((ph.astype(np.int64) - want + 2 ** 31) % 2 ** 32) - 2 ** 31
             assert np.abs(err).max() < 2 ** 12, (i, j)
+
+
+def test_rust_sys_crate_declares_the_same_abi():
+    """bindings/rust/rtfhe-sys is source only (no Rust toolchain here); keep its extern block in step with the header."""
+    hdr = open(os.path.join(ROOT, "include", "rtfhe.h")).read()
+    rs = open(os.path.join(ROOT, "bindings", "rust", "rtfhe-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"\b(rtfhe_[a-z0-9_]+)\s*\(", hdr))
+    rust = set(re.findall(r"pub fn (rtfhe_[a-z0-9_]+)\s*\(", rs))
+    assert declared == rust, declared ^ rust
+    fields = re.findall(r"pub (\w+): i32", rs.split("pub struct rtfhe_params")[1].split("}")[0])
+    assert fields == ["n", "N", "nbit", "l", "bgbit", "ks_t", "ks_basebit"]
