@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gates", type=int, default=1024, help="gates per GPU per step (BASELINE configs[1]: 1024)")
+    ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact"], default="fft64-mirror",
+                    help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-gates-per-thread", type=int, default=8)
     args = ap.parse_args()
@@ -96,6 +98,8 @@ def main():
     eng = R.Engine(params, dev)
     eng.load_bk_torus(bk)
     eng.load_ksk(ksk)
+    if args.backend == "ntt-exact":
+        eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
 
     G = args.gates
     rng = np.random.default_rng(1000 + rank)
@@ -141,20 +145,20 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "batch of %d independent HomNAND gates per GPU per step, N=1024, n=635, l=3, Bgbit=6, "
                                    "ks t=8 basebit=2 (BASELINE configs[1])" % G,
-                       "gates_per_gpu": G, "backend": "fft64-mirror", "sharding": "independent gate batches, replicated keys"},
+                       "gates_per_gpu": G, "backend": args.backend, "sharding": "independent gate batches, replicated keys"},
             "outputs_decrypt_correctly": ok and bad == 0.0,
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-                         "kernel": "k_bootstrap", "avg_launch_ms": round(1e3 * launch_s, 3),
+                         "kernel": "k_bootstrap" if args.backend == "fft64-mirror" else "k_bootstrap_ntt", "avg_launch_ms": round(1e3 * launch_s, 3),
                          "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 j = json.load(f)
-            if j.get("gates_per_launch") == G:
+            if j.get("gates_per_launch") == G and args.backend == "fft64-mirror":
                 line["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.backend == "fft64-mirror":
             line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
         print(json.dumps(line), flush=True)
     if dist is not None:

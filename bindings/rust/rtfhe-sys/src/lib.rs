@@ -23,6 +23,9 @@ pub const RTFHE_NOT: c_int = 4;
 pub const RTFHE_COPY: c_int = 5;
 pub const RTFHE_ANDNY: c_int = 6;
 
+pub const RTFHE_BACKEND_FFT64_MIRROR: c_int = 0;
+pub const RTFHE_BACKEND_NTT_EXACT: c_int = 1;
+
 pub const RTFHE_OK: c_int = 0;
 pub const RTFHE_ERR_INVALID: c_int = -1;
 pub const RTFHE_ERR_NO_DEVICE: c_int = -2;
@@ -37,6 +40,8 @@ extern "C" {
     pub fn rtfhe_last_error(ctx: *const rtfhe_ctx) -> *const c_char;
     pub fn rtfhe_version() -> *const c_char;
     pub fn rtfhe_device_count() -> c_int;
+    pub fn rtfhe_set_backend(ctx: *mut rtfhe_ctx, backend: c_int) -> c_int;
+    pub fn rtfhe_get_backend(ctx: *const rtfhe_ctx) -> c_int;
     pub fn rtfhe_get_twiddles(ctx: *const rtfhe_ctx, ifft_table: *mut f64, fft_table: *mut f64) -> c_int;
     pub fn rtfhe_set_twiddles(ctx: *mut rtfhe_ctx, ifft_table: *const f64, fft_table: *const f64) -> c_int;
 

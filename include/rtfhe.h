@@ -74,6 +74,15 @@ typedef enum {
     RTFHE_ERR_NOMEM = -5
 } rtfhe_status;
 
+/* polynomial-multiply backend of the external product */
+typedef enum {
+    RTFHE_BACKEND_FFT64_MIRROR = 0,  /* default: FP64 transform mirroring the reference's spqlios operation for operation;
+                                        outputs bit-identical to the reference CPU path */
+    RTFHE_BACKEND_NTT_EXACT = 1      /* exact negacyclic NTT mod P = 2^50 - 16383 (N = 1024): reference semantics of the exact
+                                        Polynomial::cross (utils/src/math.rs:238-257); bit-identical to an exact-integer
+                                        evaluation, decrypt-level parity with the reference's FFT path */
+} rtfhe_backend;
+
 /* ---- context ---- */
 void rtfhe_default_params(rtfhe_params *p);
 int rtfhe_ctx_create(const rtfhe_params *p, int device_id, rtfhe_ctx **out);
@@ -81,6 +90,9 @@ void rtfhe_ctx_destroy(rtfhe_ctx *ctx);
 const char *rtfhe_last_error(const rtfhe_ctx *ctx);   /* ctx may be NULL: last ctx-less error */
 const char *rtfhe_version(void);
 int rtfhe_device_count(void);
+int rtfhe_set_backend(rtfhe_ctx *ctx, int backend);   /* takes effect for subsequent calls; the NTT-domain key is derived from
+                                                         the torus-form key (rtfhe_load_bk_torus) on first use */
+int rtfhe_get_backend(const rtfhe_ctx *ctx);
 /* twiddle tables in the reference's memory layout (2N doubles each direction; blocks 4 cos | 4 sin) */
 int rtfhe_get_twiddles(const rtfhe_ctx *ctx, double *ifft_table, double *fft_table);
 int rtfhe_set_twiddles(rtfhe_ctx *ctx, const double *ifft_table, const double *fft_table);

@@ -30,6 +30,7 @@ class Params(C.Structure):
 
 
 NAND, AND, OR, XOR, NOT, COPY, ANDNY = range(7)
+BACKEND_FFT64_MIRROR, BACKEND_NTT_EXACT = 0, 1
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
 _SIGNATURES = {
@@ -39,6 +40,8 @@ _SIGNATURES = {
     "rtfhe_last_error": (C.c_char_p, [C.c_void_p]),
     "rtfhe_version": (C.c_char_p, []),
     "rtfhe_device_count": (C.c_int, []),
+    "rtfhe_set_backend": (C.c_int, [C.c_void_p, C.c_int]),
+    "rtfhe_get_backend": (C.c_int, [C.c_void_p]),
     "rtfhe_get_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_set_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_load_bk_torus": (C.c_int, [C.c_void_p, C.c_void_p]),

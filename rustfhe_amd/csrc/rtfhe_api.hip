@@ -13,6 +13,7 @@
 
 #include "rtfhe_kernels.hpp"
 #include "rtfhe_kernels_wg.hpp"
+#include "rtfhe_kernels_ntt.hpp"
 
 using namespace rtfhe;
 
@@ -159,6 +160,11 @@ struct rtfhe_ctx {
     HostTw tw;
     cplx* d_tw = nullptr;
     cplx* d_bk = nullptr;
+    int backend = RTFHE_BACKEND_FFT64_MIRROR;
+    uint32_t* d_bk_torus = nullptr;   // kept when the key came in torus form: source for the NTT-domain key
+    double* d_ntt_bk = nullptr;
+    double* d_ntt_tw = nullptr;
+    bool ntt_ready = false;
     uint32_t* d_ksk = nullptr;
     int ksw = 0;
     bool has_bk = false, has_ksk = false;
@@ -249,6 +255,73 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     }
 }
 
+// ---- exact-integer NTT backend: host tables (rtfhe_ntt.hpp; validated by scripts/ntt/model.py) ----
+typedef unsigned __int128 u128;
+uint64_t mulmod_p(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % ntt::P_U64); }
+uint64_t powmod_p(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = mulmod_p(r, a); a = mulmod_p(a, a); e >>= 1; } return r; }
+double centred_p(uint64_t x) { return x > ntt::P_U64 / 2 ? -(double)(ntt::P_U64 - x) : (double)x; }
+int bitrev10(int x) { int r = 0; for (int i = 0; i < 10; i++) r |= ((x >> i) & 1) << (9 - i); return r; }
+
+// zeta_k = psi^bitrev(k), k = (blocks of the stage) + block; device order: pass 1 [15], pass 2 [15][16], pass 3 [12][64]
+std::vector<double> ntt_device_table() {
+    const uint64_t psi = powmod_p(22, (ntt::P_U64 - 1) / (2 * ntt::N));      // 22 generates F_P^*
+    std::vector<uint64_t> zeta(ntt::N), zinv(ntt::N);
+    for (int k = 1; k < ntt::N; k++) { zeta[k] = powmod_p(psi, (uint64_t)bitrev10(k)); zinv[k] = powmod_p(zeta[k], ntt::P_U64 - 2); }
+    std::vector<double> t(ntt::TW_TOTAL, 0.0);
+    for (int dir = 0; dir < 2; dir++) {
+        const std::vector<uint64_t>& z = dir ? zinv : zeta;
+        double* d = t.data() + dir * ntt::TW_DIR_PAD;
+        for (int e = 0; e < 15; e++) d[ntt::TW_P1 + e] = centred_p(z[e + 1]);
+        for (int mb = 3; mb >= 0; mb--) {
+            const int nb = 8 >> mb;
+            for (int idx = 0; idx < nb; idx++)
+                for (int B = 0; B < 16; B++)
+                    d[ntt::TW_P2 + (nb - 1 + idx) * 16 + B] = centred_p(z[(128 >> mb) + (B << (3 - mb)) + idx]);
+        }
+        for (int v = 0; v < 64; v++) {
+            for (int e = 0; e < 4; e++) d[ntt::TW_P3 + e * 64 + v] = centred_p(z[256 + 4 * v + e]);
+            for (int e = 0; e < 8; e++) d[ntt::TW_P3 + (4 + e) * 64 + v] = centred_p(z[512 + 8 * v + e]);
+        }
+    }
+    return t;
+}
+
+int ntt_prepare(rtfhe_ctx* ctx) {
+    if (ctx->ntt_ready) return 0;
+    if (ctx->p.N != ntt::N) return fail(ctx, RTFHE_ERR_INVALID, "the NTT backend supports N = 1024");
+    if (!ctx->d_bk_torus) return fail(ctx, RTFHE_ERR_STATE, "the NTT backend needs the bootstrapping key in torus form (rtfhe_load_bk_torus)");
+    if (!ctx->d_ntt_tw) {
+        std::vector<double> t = ntt_device_table();
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ntt_tw, t.size() * sizeof(double)));
+        HIPCHECK(ctx, hipMemcpy(ctx->d_ntt_tw, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const size_t words = bk_word_count(ctx->p);
+    if (!ctx->d_ntt_bk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ntt_bk, words * sizeof(double)));
+    constexpr int W = 4;
+    NttBkArgs a{ctx->d_ntt_tw, ctx->d_bk_torus, ctx->d_ntt_bk, (int32_t)(words / ctx->p.N), 2 * ctx->p.l,
+                centred_p(powmod_p(ntt::N, ntt::P_U64 - 2))};
+    const size_t lds = (size_t)(ntt::TW_DIR_PAD + W * ntt::XSLOTS) * sizeof(double);
+    if (int rc = allow_lds(ctx, k_ntt_bk<W>, lds)) return rc;
+    int grid = (a.count + W - 1) / W; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_ntt_bk<W>, dim3(grid), dim3(64 * W), lds, ctx->stream, a);
+    HIPCHECK(ctx, hipGetLastError());
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ntt_ready = true;
+    return 0;
+}
+
+template <int W>
+int launch_bootstrap_ntt_w(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_ntt<3, 6, 8, 2, KSQ, W>;
+    const size_t lds = ntt_lds_bytes(W, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    NttBootstrapArgs a{b, ctx->d_ntt_tw, ctx->d_ntt_bk};
+    hipLaunchKernelGGL(k, dim3((b.count + W - 1) / W), dim3(64 * W), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
 int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
                      size_t count, hipStream_t s, const int32_t* d_ops = nullptr, const int32_t* d_idx0 = nullptr,
                      const int32_t* d_idx1 = nullptr, const int32_t* d_idx_out = nullptr) {
@@ -263,6 +336,10 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.npad = (ctx->p.n + 1 + 63) / 64 * 64;
     a.ops = d_ops; a.idx0 = d_idx0; a.idx1 = d_idx1; a.idx_out = d_idx_out;
     a.dbg = ctx->d_dbg;
+    if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
+        if (int rc = ntt_prepare(ctx)) return rc;
+        return launch_bootstrap_ntt_w<4>(ctx, a, s);   // 6-wave workgroups measured slower (64 k vs 76 k gates/s): LDS-bound
+    }
     return ctx->logn == 10 ? launch_bootstrap_t<10>(ctx, a, s) : launch_bootstrap_t<11>(ctx, a, s);
 }
 
@@ -399,6 +476,9 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_bk) (void)hipFree(ctx->d_bk);
+    if (ctx->d_bk_torus) (void)hipFree(ctx->d_bk_torus);
+    if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
+    if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);
     if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_b) (void)hipFree(ctx->d_b);
@@ -408,6 +488,16 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+
+int rtfhe_set_backend(rtfhe_ctx* ctx, int backend) {
+    if (int rc = use(ctx)) return rc;
+    if (backend != RTFHE_BACKEND_FFT64_MIRROR && backend != RTFHE_BACKEND_NTT_EXACT) return fail(ctx, RTFHE_ERR_INVALID, "unknown backend");
+    if (backend == RTFHE_BACKEND_NTT_EXACT && ctx->p.N != ntt::N) return fail(ctx, RTFHE_ERR_INVALID, "the NTT backend supports N = 1024");
+    ctx->backend = backend;
+    return 0;
+}
+
+int rtfhe_get_backend(const rtfhe_ctx* ctx) { return ctx ? ctx->backend : RTFHE_ERR_INVALID; }
 
 int rtfhe_get_twiddles(const rtfhe_ctx* ctx, double* ifft_table, double* fft_table) {
     if (!ctx || !ifft_table || !fft_table) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
@@ -430,6 +520,9 @@ int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
     if (!ctx->d_bk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx)));
     if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, words * 4)) return rc;
     HIPCHECK(ctx, hipMemcpy(ctx->d_a, bk, words * 4, hipMemcpyHostToDevice));
+    if (!ctx->d_bk_torus) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_bk_torus, words * 4));
+    HIPCHECK(ctx, hipMemcpy(ctx->d_bk_torus, ctx->d_a, words * 4, hipMemcpyDeviceToDevice));
+    ctx->ntt_ready = false;
     // TRGSWRepF::from (trgsw.rs:68-76): ifft_torus = forward transform of the words viewed as signed i32
     FftArgs a{ctx->d_tw, ctx->d_a, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l};
     if (int rc = launch_fft(ctx, true, a, ctx->stream)) return rc;
@@ -450,6 +543,8 @@ int rtfhe_load_bk_fft(rtfhe_ctx* ctx, const double* bk_f) {
                              : launch_permute_t<11>(ctx, (const double*)ctx->d_a, (double*)ctx->d_bk, polys, 0, 2 * ctx->p.l, ctx->stream);
     if (rc) return rc;
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_bk_torus) { (void)hipFree(ctx->d_bk_torus); ctx->d_bk_torus = nullptr; }   // no torus form of this key
+    ctx->ntt_ready = false;
     ctx->has_bk = true;
     return 0;
 }
@@ -584,9 +679,20 @@ int rtfhe_external_product_batch(rtfhe_ctx* ctx, const int32_t* bk_index, const 
     if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, bytes)) return rc;
     HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, trlwe, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(ctx, hipMemcpyAsync(ctx->d_b, bk_index, count * 4, hipMemcpyHostToDevice, ctx->stream));
-    ExtProdArgs a{ctx->d_tw, ctx->d_bk, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count};
-    int rc = ctx->logn == 10 ? launch_extprod_t<10>(ctx, a, ctx->stream) : launch_extprod_t<11>(ctx, a, ctx->stream);
-    if (rc) return rc;
+    int rc;
+    if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
+        if ((rc = ntt_prepare(ctx))) return rc;
+        constexpr int W = 4;
+        NttExtProdArgs a{ctx->d_ntt_tw, ctx->d_ntt_bk, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count};
+        const size_t lds = ntt_lds_bytes(W, 0);
+        if ((rc = allow_lds(ctx, k_external_product_ntt<3, 6, W>, lds))) return rc;
+        hipLaunchKernelGGL((k_external_product_ntt<3, 6, W>), dim3((a.count + W - 1) / W), dim3(64 * W), lds, ctx->stream, a);
+        HIPCHECK(ctx, hipGetLastError());
+    } else {
+        ExtProdArgs a{ctx->d_tw, ctx->d_bk, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count};
+        rc = ctx->logn == 10 ? launch_extprod_t<10>(ctx, a, ctx->stream) : launch_extprod_t<11>(ctx, a, ctx->stream);
+        if (rc) return rc;
+    }
     HIPCHECK(ctx, hipMemcpyAsync(out, ctx->d_c, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

@@ -1,0 +1,212 @@
+// rtfhe_kernels_ntt.hpp -- the bootstrap kernel on the exact-integer NTT backend (rtfhe_ntt.hpp).  Same gate pipeline
+// as k_bootstrap (pre-step, blind rotate, sample extract, key switch; one wave per gate) with the FP64-FFT mirror
+// replaced by exact products mod P.  Integer glue (rotate, decomposition, mod switch, key switch) is shared.
+#pragma once
+
+#include "rtfhe_kernels.hpp"
+#include "rtfhe_ntt.hpp"
+
+namespace rtfhe {
+
+// BK in the NTT domain, device layout: double[n][2l rows][2 comp][8][64 lanes][2]: lane v holds points 16 v + m (layout L3),
+// (m = 2 q + e) at [q][v][e]; N^-1 folded in; centred residues.
+__device__ __forceinline__ const double2* ntt_bk_row(const double* bk_i, int row, int comp, int lane) {
+    return reinterpret_cast<const double2*>(bk_i + ((size_t)(row * 2 + comp) * ntt::N)) + lane;
+}
+
+template <int L, int BGBIT, bool CMUX>
+__device__ __forceinline__ void cmux_step_ntt(uint32_t* __restrict__ accbuf, int r, const double* __restrict__ bk_i,
+                                              const double* __restrict__ twf, const double* __restrict__ twi,
+                                              double* __restrict__ xbuf, int lane) {
+    constexpr int N = ntt::N, R = ntt::R;
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    double s0[R], s1[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) { s0[m] = 0.0; s1[m] = 0.0; }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        const uint32_t* poly = accbuf + h * N;
+        uint32_t u[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            const uint32_t own = poly[c];
+            const uint32_t d = CMUX ? (rotated_coef<10>(poly, c, r) - own) : own;
+            u[m] = (d + M) ^ M;
+        }
+#pragma unroll 1
+        for (int jj = 0; jj < L; jj++) {
+            double x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) x[m] = (double)decomp_digit(u[m], BGBIT, jj);
+            const double2* b0p = ntt_bk_row(bk_i, h * L + jj, 0, lane);
+            const double2* b1p = ntt_bk_row(bk_i, h * L + jj, 1, lane);
+            double2 b0[R / 2], b1[R / 2];
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
+            ntt::forward(x, twf, xbuf, lane);
+            // exact arithmetic: the order of the row sum is irrelevant here (it is not for the FFT mirror)
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) {
+                s0[2 * q] += ntt::modmul(x[2 * q], b0[q].x);     s0[2 * q + 1] += ntt::modmul(x[2 * q + 1], b0[q].y);
+                s1[2 * q] += ntt::modmul(x[2 * q], b1[q].x);     s1[2 * q + 1] += ntt::modmul(x[2 * q + 1], b1[q].y);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int comp = 0; comp < 2; comp++) {
+        double x[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) x[m] = comp ? s1[m] : s0[m];
+        ntt::inverse(x, twi, xbuf, lane);
+        uint32_t* poly = accbuf + comp * N;
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            if (CMUX) poly[c] += ntt::to_torus(x[m]);
+            else poly[c] = ntt::to_torus(x[m]);
+        }
+    }
+    wave_lds_sync();
+}
+
+__host__ __device__ constexpr size_t ntt_wave_lds_bytes(int npad) {
+    return (size_t)ntt::XSLOTS * sizeof(double) + (size_t)2 * ntt::N * 4 + (size_t)npad * 4;
+}
+__host__ __device__ constexpr size_t ntt_lds_bytes(int waves, int npad) {
+    return (size_t)ntt::TW_TOTAL * sizeof(double) + (size_t)waves * ntt_wave_lds_bytes(npad);
+}
+
+struct NttBootstrapArgs {
+    BootstrapArgs b;          // tw and bk of `b` are unused here
+    const double* ntt_tw;     // [ntt::TW_TOTAL]
+    const double* ntt_bk;     // device layout above
+};
+
+template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap_ntt(const NttBootstrapArgs args) {
+    constexpr int N = ntt::N, R = ntt::R, LOGN = 10;
+    const BootstrapArgs& a = args.b;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < ntt::TW_TOTAL; idx += 64 * WAVES) tw[idx] = args.ntt_tw[idx];
+    __syncthreads();
+    const int g = blockIdx.x * WAVES + wave;
+    if (g >= a.count) return;
+    unsigned char* wbase = smem + (size_t)ntt::TW_TOTAL * sizeof(double) + (size_t)wave * ntt_wave_lds_bytes(a.npad);
+    double* xbuf = reinterpret_cast<double*>(wbase);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)ntt::XSLOTS * sizeof(double));
+    uint32_t* abar = accbuf + 2 * N;
+    const double* twf = tw;
+    const double* twi = tw + ntt::TW_DIR_PAD;
+    const int n = a.n;
+    {
+        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
+        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
+        const int op = a.ops ? a.ops[g] : a.op;
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane; i <= n; i += 64) {
+            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
+        }
+    }
+    wave_lds_sync();
+    {
+        const int bbar = (int)abar[n];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            const int e = (c + bbar) & (2 * N - 1);
+            accbuf[c] = (e >> LOGN) ? 0xE0000000u : 0x20000000u;
+            accbuf[N + c] = 0u;
+        }
+    }
+    wave_lds_sync();
+    const size_t trgsw_doubles = (size_t)2 * L * 2 * N;
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        cmux_step_ntt<L, BGBIT, true>(accbuf, r, args.ntt_bk + (size_t)i * trgsw_doubles, twf, twi, xbuf, lane);
+    }
+    if (a.mode == MODE_BLIND_ROTATE) {
+        uint32_t* o = a.out + (size_t)g * 2 * N;
+        for (int c = lane; c < 2 * N; c += 64) o[c] = accbuf[c];
+        return;
+    }
+    uint32_t av[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) av[m] = accbuf[N + lane + 64 * m];
+    const uint32_t bprime = accbuf[0];
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const int c = lane + 64 * m;
+        accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[m] : (0u - av[m]);
+    }
+    wave_lds_sync();
+    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n,
+                                            a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1), lane);
+}
+
+struct NttBkArgs {
+    const double* ntt_tw;
+    const uint32_t* bk_torus;   // [n][2][2l][N]
+    double* ntt_bk;             // device layout
+    int32_t count;              // polynomials
+    int32_t rows;               // 2l
+    double ninv;                // N^-1 mod P, centred
+};
+
+// key rows -> NTT domain (the counterpart of TRGSWRepF::from, hom_nand/src/trgsw.rs:68-76): words viewed as signed i32
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_ntt_bk(const NttBkArgs a) {
+    constexpr int N = ntt::N, R = ntt::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < ntt::TW_DIR_PAD; idx += 64 * WAVES) tw[idx] = a.ntt_tw[idx];
+    __syncthreads();
+    double* xbuf = tw + ntt::TW_DIR_PAD + (size_t)wave * ntt::XSLOTS;
+    for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
+        const int32_t* src = reinterpret_cast<const int32_t*>(a.bk_torus) + (size_t)g * N;
+        double x[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) x[m] = (double)src[lane + 64 * m];
+        ntt::forward(x, tw, xbuf, lane);
+        double2* dst = reinterpret_cast<double2*>(a.ntt_bk + bk_poly_remap((size_t)g, a.rows) * N) + lane;
+#pragma unroll
+        for (int q = 0; q < R / 2; q++)
+            dst[q * 64] = make_double2(ntt::normalize(ntt::modmul(x[2 * q], a.ninv)), ntt::normalize(ntt::modmul(x[2 * q + 1], a.ninv)));
+    }
+}
+
+struct NttExtProdArgs {
+    const double* ntt_tw;
+    const double* ntt_bk;
+    const int32_t* bk_index;
+    const uint32_t* trlwe;
+    uint32_t* out;
+    int32_t count;
+};
+
+template <int L, int BGBIT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_external_product_ntt(const NttExtProdArgs a) {
+    constexpr int N = ntt::N;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < ntt::TW_TOTAL; idx += 64 * WAVES) tw[idx] = a.ntt_tw[idx];
+    __syncthreads();
+    const int g = blockIdx.x * WAVES + wave;
+    if (g >= a.count) return;
+    unsigned char* wbase = smem + (size_t)ntt::TW_TOTAL * sizeof(double) + (size_t)wave * ntt_wave_lds_bytes(0);
+    double* xbuf = reinterpret_cast<double*>(wbase);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(wbase + (size_t)ntt::XSLOTS * sizeof(double));
+    for (int c = lane; c < 2 * N; c += 64) accbuf[c] = a.trlwe[(size_t)g * 2 * N + c];
+    wave_lds_sync();
+    cmux_step_ntt<L, BGBIT, false>(accbuf, 0, a.ntt_bk + (size_t)a.bk_index[g] * ((size_t)2 * L * 2 * N), tw, tw + ntt::TW_DIR_PAD, xbuf, lane);
+    for (int c = lane; c < 2 * N; c += 64) a.out[(size_t)g * 2 * N + c] = accbuf[c];
+}
+
+}  // namespace rtfhe

@@ -1,0 +1,173 @@
+// rtfhe_ntt.hpp -- exact-integer multiply backend: negacyclic NTT over F_P, P = 2^50 - 16383, N = 1024.
+//
+// This is the second multiply backend (the one BASELINE's north_star names).  It computes
+// the external product's polynomial products EXACTLY (reference semantics of Polynomial::cross, utils/src/math.rs:238-257),
+// so its outputs are bit-identical to the oracle's `exact_int` backend -- and therefore NOT to the reference CPU path,
+// whose FP64 FFT + truncation deviates from exact arithmetic by +-1 LSB per external product.  Against
+// the reference it gives identical decrypted bits and phases within the noise margin.
+//
+// Arithmetic: doubles holding exact integers (|x| < 2^53), modular product by an error-free FMA split:
+//   h = a*w ; l = fma(a, w, -h) ; q = rint(h / P) ; r = fma(-q, P, h) + l        (6 FP64 ops, r == a*w (mod P), |r| < 2.2 P)
+// Transforms with the negacyclic twist merged into per-block twiddles (zeta_k = psi^bitrev(k)):
+//   forward  Cooley-Tukey butterflies (t = zeta x1 ; x0 +- t), stride N/2 .. 1, natural in  -> bit-reversed out
+//   inverse  Gentleman-Sande butterflies (x0 + x1 ; zeta^-1 (x0 - x1)), stride 1 .. N/2, bit-reversed in -> natural out
+// Bounds (scripts/ntt/model.py runs the same operation sequence on exact integers and asserts them): values are
+// renormalised to |x| <= P/2 after every register pass (forward) / every second stage (inverse), which keeps every
+// intermediate below 2^53; the true result of a gate's sum of 2l products is below 2^48.6 < P/2, so the centred
+// residue IS the integer result.  N^-1 is folded into the key's transformed rows.
+//
+// One wave per transform, 16 points per lane, three in-register passes (4 + 4 + 2 stages) with two wave-private LDS
+// exchanges: the index geometry (layouts L1/L2/L3, conflict-free slot maps f1/f2) is Geo<11>'s (1024 points, R = 16).
+#pragma once
+
+#include "rtfhe_device.hpp"
+
+namespace rtfhe {
+namespace ntt {
+
+typedef Geo<11> GN;                       // 1024 points on 64 lanes: R = 16, LR = 4, LOW = 2
+constexpr int N = 1024;
+constexpr int R = 16;
+constexpr double P = 1125899906826241.0;  // 2^50 - 16383, prime, 2^14 | P - 1
+constexpr unsigned long long P_U64 = 1125899906826241ull;
+constexpr double PINV = 1.0 / 1125899906826241.0;
+
+// twiddle table (doubles), one per direction: [pass 1: 15 wave-uniform][pass 2: 15 x 16 lane groups][pass 3: 12 x 64 lanes]
+constexpr int TW_P1 = 0;
+constexpr int TW_P2 = TW_P1 + 15;
+constexpr int TW_P3 = TW_P2 + 15 * 16;
+constexpr int TW_DIR = TW_P3 + 12 * 64;   // 1023 = N - 1 zetas
+constexpr int TW_DIR_PAD = 1024;          // keep the inverse table 16-byte aligned
+constexpr int TW_TOTAL = 2 * TW_DIR_PAD;
+constexpr int XSLOTS = GN::XSLOTS;        // 1088 doubles
+
+__device__ __forceinline__ double modmul(double a, double w) {
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double q = __builtin_rint(h * PINV);
+    return __builtin_fma(-q, P, h) + l;
+}
+__device__ __forceinline__ double normalize(double x) {
+    return __builtin_fma(-__builtin_rint(x * PINV), P, x);
+}
+template <int CNT>
+__device__ __forceinline__ void normalize_all(double (&x)[CNT]) {
+#pragma unroll
+    for (int m = 0; m < CNT; m++) x[m] = normalize(x[m]);
+}
+
+// Cooley-Tukey stage on register bit MB; zeta index = (nb - 1) + (m >> (MB + 1)), nb = R >> (MB + 1)
+template <int MB>
+__device__ __forceinline__ void fwd_stage(double (&x)[R], const double* z) {
+    constexpr int h = 1 << MB, nb = R >> (MB + 1);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & h) continue;
+        const double t = modmul(x[m | h], z[nb - 1 + (m >> (MB + 1))]);
+        x[m | h] = x[m] - t;
+        x[m] = x[m] + t;
+    }
+}
+// Gentleman-Sande stage
+template <int MB>
+__device__ __forceinline__ void inv_stage(double (&x)[R], const double* z) {
+    constexpr int h = 1 << MB, nb = R >> (MB + 1);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & h) continue;
+        const double u = x[m], v = x[m | h];
+        x[m] = u + v;
+        x[m | h] = modmul(u - v, z[nb - 1 + (m >> (MB + 1))]);
+    }
+}
+
+template <int FROM, int TO>
+__device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xbuf, int lane) {
+    auto slot = [&](int layout, int m) {
+        const int pos = layout == 1 ? GN::pos1(lane, m) : layout == 2 ? GN::pos2(lane, m) : GN::pos3(lane, m);
+        return (FROM + TO == 3) ? GN::f1(pos) : GN::f2(pos);
+    };
+#pragma unroll
+    for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = x[m];
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < R; m++) x[m] = xbuf[slot(TO, m)];
+    wave_lds_sync();
+}
+
+// in: layout L1 (x[m] = coefficient lane + 64 m), small integers or |x| < 2^32.  out: layout L3 (point (lane << 4) | m),
+// normalised.  tw: LDS forward table.
+__device__ __forceinline__ void forward(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    double z1[15], z2[15], z3[12];
+#pragma unroll
+    for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
+    fwd_stage<3>(x, z1); fwd_stage<2>(x, z1); fwd_stage<1>(x, z1); fwd_stage<0>(x, z1);
+    normalize_all(x);
+#pragma unroll
+    for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
+    exchange<1, 2>(x, xbuf, lane);
+    fwd_stage<3>(x, z2); fwd_stage<2>(x, z2); fwd_stage<1>(x, z2); fwd_stage<0>(x, z2);
+    normalize_all(x);
+#pragma unroll
+    for (int e = 0; e < 12; e++) z3[e] = tw[TW_P3 + e * 64 + lane];
+    exchange<2, 3>(x, xbuf, lane);
+    // pass 3 touches register bits 1 and 0 only: zeta index 4 (m >> 2) .. for bit 1 -> entries 0..3, bit 0 -> entries 4..11
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & 2) continue;
+        const double t = modmul(x[m | 2], z3[m >> 2]);
+        x[m | 2] = x[m] - t;
+        x[m] = x[m] + t;
+    }
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double t = modmul(x[m + 1], z3[4 + (m >> 1)]);
+        x[m + 1] = x[m] - t;
+        x[m] = x[m] + t;
+    }
+    normalize_all(x);
+}
+
+// in: layout L3, |x| < 2^52.  out: layout L1, the centred residue (= the exact integer when |true value| < P/2).
+__device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    double z1[15], z2[15], z3[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) z3[e] = tw[TW_P3 + e * 64 + lane];
+    normalize_all(x);
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double u = x[m], v = x[m + 1];
+        x[m] = u + v;
+        x[m + 1] = modmul(u - v, z3[4 + (m >> 1)]);
+    }
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & 2) continue;
+        const double u = x[m], v = x[m | 2];
+        x[m] = u + v;
+        x[m | 2] = modmul(u - v, z3[m >> 2]);
+    }
+    normalize_all(x);
+#pragma unroll
+    for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
+    exchange<3, 2>(x, xbuf, lane);
+    inv_stage<0>(x, z2); inv_stage<1>(x, z2);
+    normalize_all(x);
+    inv_stage<2>(x, z2); inv_stage<3>(x, z2);
+    normalize_all(x);
+#pragma unroll
+    for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
+    exchange<2, 1>(x, xbuf, lane);
+    inv_stage<0>(x, z1); inv_stage<1>(x, z1);
+    normalize_all(x);
+    inv_stage<2>(x, z1); inv_stage<3>(x, z1);
+    normalize_all(x);
+}
+
+// exact integer (|x| < 2^51) -> torus word: the low 32 bits of the two's-complement value
+__device__ __forceinline__ uint32_t to_torus(double x) {
+    return (uint32_t)__double_as_longlong(x + 6755399441055744.0);
+}
+
+}  // namespace ntt
+}  // namespace rtfhe

@@ -73,6 +73,12 @@ class Engine:
         assert ksk.size == self.p.ksk_words, "ksk must be u32[N][t][base-1][n+1]"
         self._ck(self.L.rtfhe_load_ksk(self.h, _ptr(ksk)))
 
+    def set_backend(self, backend):
+        self._ck(self.L.rtfhe_set_backend(self.h, backend))
+
+    def backend(self):
+        return self.L.rtfhe_get_backend(self.h)
+
     def twiddles(self):
         a = np.zeros(2 * self.p.N, np.float64)
         b = np.zeros(2 * self.p.N, np.float64)

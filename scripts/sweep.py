@@ -12,6 +12,8 @@ P = R.Params(N=int(os.environ.get('RTFHE_N', '1024')))
 key0, key1, bk, ksk = R.keygen(P, 20211003)
 eng = R.Engine(P, 0)
 eng.load_bk_torus(bk); eng.load_ksk(ksk)
+if os.environ.get('RTFHE_BACKEND') == 'ntt':
+    eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
 G = max(counts)
 rng = np.random.default_rng(0)
 b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)

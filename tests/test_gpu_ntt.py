@@ -1,0 +1,98 @@
+"""GPU: the exact-integer NTT multiply backend (rtfhe_set_backend(RTFHE_BACKEND_NTT_EXACT)).  Its polynomial products are
+exact, so it is bit-identical to the oracle's exact-integer backend (schoolbook negacyclic products, the semantics of the
+reference's Polynomial::cross, utils/src/math.rs:238-257) -- and only decrypt-/phase-equivalent to the reference's FP64-FFT
+path, which is what the default fft64-mirror backend reproduces bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ntt_engine(params, keys):
+    import rustfhe_amd as R
+    e = R.Engine(R.Params(), 0)
+    e.load_bk_torus(keys.bk_t)
+    e.load_ksk(keys.ksk)
+    e.set_backend(R._ffi.BACKEND_NTT_EXACT)
+    assert e.backend() == R._ffi.BACKEND_NTT_EXACT
+    yield e
+    e.close()
+
+
+def test_ntt_external_product_is_exact(ntt_engine, orc, params, keys):
+    rng = np.random.default_rng(71)
+    idx = np.array([0, 5, 634, 300, 17, 99], np.int32)
+    trlwe = rng.integers(0, 2 ** 32, (6, 2 * params.N), dtype=np.uint64).astype(np.uint32)
+    trlwe[1] = 0
+    trlwe[2] = 0xFFFFFFFF          # extreme digits / carries
+    trlwe[3] = 0x7DF7C000          # every digit at the top of its range
+    out = ntt_engine.external_product_batch(idx, trlwe)
+    pl = orc.Plan(params.N, orc.BACKEND_EXACT)
+    w = params.trgsw_words
+    exp = np.stack([orc.external_product(params, pl, None, keys.bk_t[i * w:(i + 1) * w], t) for i, t in zip(idx, trlwe)])
+    assert np.array_equal(out.reshape(exp.shape), exp)
+
+
+@pytest.mark.parametrize("steps", [1, 4, 23])
+def test_ntt_blind_rotate_prefix_is_exact(ntt_engine, orc, params, keys, gold_gate, steps):
+    t = np.stack([orc.gate_linear(params, orc.NAND, a, b) for a, b in zip(gold_gate["in0"][:3], gold_gate["in1"][:3])])
+    acc = ntt_engine.blind_rotate_batch(t, steps)
+    pl = orc.Plan(params.N, orc.BACKEND_EXACT)
+    exp = np.stack([orc.blind_rotate(params, pl, None, keys.bk_t, x, steps) for x in t])
+    assert np.array_equal(acc.reshape(exp.shape), exp)
+
+
+def test_ntt_whole_gate_exact_and_decrypts_like_the_reference_path(ntt_engine, engine, orc, params, keys, gold_gate):
+    import rustfhe_amd as R
+    pl = orc.Plan(params.N, orc.BACKEND_EXACT)
+    a, b = gold_gate["in0"][3], gold_gate["in1"][3]
+    out = ntt_engine.gate_batch(R.NAND, a[None], b[None])[0]
+    exp = orc.gate(params, pl, orc.NAND, None, keys.bk_t, keys.ksk, a, b)          # ~10 s: 635 steps of schoolbook products
+    assert np.array_equal(out, exp)
+    # against the reference-exact (mirror) path: different ciphertext words, same plaintext, phases within the noise
+    ref = gold_gate["out"][3]
+    assert not np.array_equal(out, ref)
+    assert keys.decrypt_bits([out]) == keys.decrypt_bits([ref])
+    d = (int(keys.phase(out)) - int(keys.phase(ref)) + 2 ** 31) % 2 ** 32 - 2 ** 31
+    assert abs(d) < 2 ** 26          # 1/64 of the torus; observed ~3e-3
+
+
+def test_ntt_batch_decrypts_and_all_shapes_agree(ntt_engine, engine, params, keys):
+    import rustfhe_amd as R
+    rng = np.random.default_rng(72)
+    G = 1536                                  # > 4 gates per CU: workgroups queue behind each other
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    out = ntt_engine.gate_batch(R.NAND, c0, c1)
+    assert keys.decrypt_bits(out) == list(1 - (b0 & b1))
+    assert np.array_equal(ntt_engine.gate_batch(R.NAND, c0[:5], c1[:5]), out[:5])
+    for op, f in ((R.XOR, lambda x, y: x ^ y), (R.OR, lambda x, y: x | y)):
+        o = ntt_engine.gate_batch(op, c0[:64], c1[:64])
+        assert keys.decrypt_bits(o) == list(f(b0[:64], b1[:64]))
+
+
+def test_backend_switch_back_to_mirror(ntt_engine, gold_gate):
+    import rustfhe_amd as R
+    ntt_engine.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+    try:
+        out = ntt_engine.gate_batch(R.NAND, gold_gate["in0"][:2], gold_gate["in1"][:2])
+        assert np.array_equal(out, gold_gate["out"][:2])
+    finally:
+        ntt_engine.set_backend(R._ffi.BACKEND_NTT_EXACT)
+    with pytest.raises(R.RtfheError):
+        ntt_engine.set_backend(7)
+
+
+def test_ntt_needs_torus_key(keys):
+    import rustfhe_amd as R
+    e = R.Engine(R.Params(), 0)
+    try:
+        e.load_bk_fft(keys.bk_f)             # FrrSeries-domain key only: no torus form to derive the NTT key from
+        e.load_ksk(keys.ksk)
+        e.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        with pytest.raises(R.RtfheError) as ei:
+            e.gate_batch(R.NAND, np.zeros((1, 636), np.uint32), np.zeros((1, 636), np.uint32))
+        assert ei.value.code == R._ffi.ERR_STATE
+    finally:
+        e.close()

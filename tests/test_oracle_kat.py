@@ -166,3 +166,11 @@ def test_exact_int_backend_decrypts_like_mirror(orc, keys):
     mir = orc.gate(small, orc.Plan(small.N), orc.NAND, kk.bk_f, None, kk.ksk, c[0], c[1])
     exa = orc.gate(small, orc.Plan(small.N, orc.BACKEND_EXACT), orc.NAND, None, kk.bk_t, kk.ksk, c[0], c[1])
     assert kk.decrypt_bits([mir]) == kk.decrypt_bits([exa]) == [1]
+
+
+def test_ntt_backend_model():
+    """scripts/ntt/model.py: the NTT backend's operation sequence on exact integers (tables, bounds < 2^53, product == exact)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ntt", "model.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
