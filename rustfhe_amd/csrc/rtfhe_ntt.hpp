@@ -12,7 +12,7 @@
 //   forward  Cooley-Tukey butterflies (t = zeta x1 ; x0 +- t), stride N/2 .. 1, natural in  -> bit-reversed out
 //   inverse  Gentleman-Sande butterflies (x0 + x1 ; zeta^-1 (x0 - x1)), stride 1 .. N/2, bit-reversed in -> natural out
 // Bounds (scripts/ntt/model.py runs the same operation sequence on exact integers and asserts them): values are
-// renormalised to |x| <= P/2 after every register pass (forward) / every second stage (inverse), which keeps every
+// renormalised to |x| <= P/2 after stages 5 and 10 (forward) / on entry and after stages 3, 6, 9, 10 (inverse), which keeps every
 // intermediate below 2^53; the true result of a gate's sum of 2l products is below 2^48.6 < P/2, so the centred
 // residue IS the integer result.  N^-1 is folded into the key's transformed rows.
 //
@@ -95,23 +95,27 @@ __device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xb
     wave_lds_sync();
 }
 
-// in: layout L1 (x[m] = coefficient lane + 64 m), small integers or |x| < 2^32.  out: layout L3 (point (lane << 4) | m),
-// normalised.  tw: LDS forward table.
-__device__ __forceinline__ void forward(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
-    double z1[15], z2[15], z3[12];
+// Forward transform in two parts so that a caller can issue its global loads between them (their registers are then
+// not live through passes 1 and 2).  in: layout L1 (x[m] = coefficient lane + 64 m), small integers or |x| < 2^32.
+// out: layout L3 (point (lane << 4) | m), normalised.  tw: LDS forward table.
+__device__ __forceinline__ void forward_a(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    double z1[15], z2[15];
 #pragma unroll
     for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
     fwd_stage<3>(x, z1); fwd_stage<2>(x, z1); fwd_stage<1>(x, z1); fwd_stage<0>(x, z1);
-    normalize_all(x);
 #pragma unroll
     for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
     exchange<1, 2>(x, xbuf, lane);
-    fwd_stage<3>(x, z2); fwd_stage<2>(x, z2); fwd_stage<1>(x, z2); fwd_stage<0>(x, z2);
-    normalize_all(x);
+    fwd_stage<3>(x, z2);
+    normalize_all(x);                 // after stage 5 (and after stage 10): every intermediate stays below 2^53 (model.py)
+    fwd_stage<2>(x, z2); fwd_stage<1>(x, z2); fwd_stage<0>(x, z2);
+}
+__device__ __forceinline__ void forward_b(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    double z3[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) z3[e] = tw[TW_P3 + e * 64 + lane];
     exchange<2, 3>(x, xbuf, lane);
-    // pass 3 touches register bits 1 and 0 only: zeta index 4 (m >> 2) .. for bit 1 -> entries 0..3, bit 0 -> entries 4..11
+    // pass 3 touches register bits 1 and 0 only: bit 1 uses entries 0..3 (index m >> 2), bit 0 entries 4..11 (index m >> 1)
 #pragma unroll
     for (int m = 0; m < R; m++) {
         if (m & 2) continue;
@@ -126,6 +130,10 @@ __device__ __forceinline__ void forward(double (&x)[R], const double* __restrict
         x[m] = x[m] + t;
     }
     normalize_all(x);
+}
+__device__ __forceinline__ void forward(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    forward_a(x, tw, xbuf, lane);
+    forward_b(x, tw, xbuf, lane);
 }
 
 // in: layout L3, |x| < 2^52.  out: layout L1, the centred residue (= the exact integer when |true value| < P/2).
@@ -147,20 +155,19 @@ __device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict
         x[m] = u + v;
         x[m | 2] = modmul(u - v, z3[m >> 2]);
     }
-    normalize_all(x);
 #pragma unroll
     for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
     exchange<3, 2>(x, xbuf, lane);
-    inv_stage<0>(x, z2); inv_stage<1>(x, z2);
-    normalize_all(x);
-    inv_stage<2>(x, z2); inv_stage<3>(x, z2);
+    inv_stage<0>(x, z2);
+    normalize_all(x);                 // sums double per stage: renormalise after stages 3, 6, 9 and 10 (model.py)
+    inv_stage<1>(x, z2); inv_stage<2>(x, z2); inv_stage<3>(x, z2);
     normalize_all(x);
 #pragma unroll
     for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
     exchange<2, 1>(x, xbuf, lane);
-    inv_stage<0>(x, z1); inv_stage<1>(x, z1);
+    inv_stage<0>(x, z1); inv_stage<1>(x, z1); inv_stage<2>(x, z1);
     normalize_all(x);
-    inv_stage<2>(x, z1); inv_stage<3>(x, z1);
+    inv_stage<3>(x, z1);
     normalize_all(x);
 }
 

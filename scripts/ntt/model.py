@@ -37,6 +37,8 @@ for k in range(1, N):
 ZETA_INV = [0] + [center(pow(z, P - 2, P)) for z in ZETA[1:]]
 NINV = pow(N, P - 2, P)
 
+FWD_NORM = (5, 10)       # device: after the first stage of pass 2, and at the end
+INV_NORM = (3, 6, 9, 10) # device: plus one normalisation of the input sums
 stats = {"max_abs": 0}
 def track(v):
     a = abs(v)
@@ -69,7 +71,7 @@ def forward(a):
                 a[j + h] = track(a[j] - t)
                 a[j] = track(a[j] + t)
         stage += 1
-        if stage in (4, 8, 10):              # end of each register pass: 4 + 4 + 2 stages
+        if stage in FWD_NORM:                # renormalisation points (stage counts)
             a = [normalize(x) for x in a]
         h //= 2
     return a
@@ -87,7 +89,7 @@ def inverse(a):
                 a[j] = track(u + v)
                 a[j + h] = modmul(track(u - v), z)
         stage += 1
-        if stage % 2 == 0:                   # sums double every stage: normalize every second one
+        if stage in INV_NORM:                # sums double every stage
             a = [normalize(x) for x in a]
         h *= 2
     return a
@@ -126,4 +128,18 @@ if __name__ == "__main__":
         exact = [x + y for x, y in zip(exact, e)]
     assert max(abs(x) for x in exact) < P // 2
     assert out == exact, "NTT product != exact negacyclic product"
+    # adversarial magnitudes: every digit -32, every key word -2^31 (largest possible true sum), and alternating signs
+    for dval, rval in ((-32, -2 ** 31), (31, 2 ** 31 - 1)):
+        for alt in (False, True):
+            rows = [[rval * (-1 if (alt and i % 2) else 1) for i in range(N)] for _ in range(6)]
+            digs = [[dval * (-1 if (alt and (i // 3) % 2) else 1) for i in range(N)] for _ in range(6)]
+            acc = [0] * N
+            for r_, d_ in zip(rows, digs):
+                fr = [center(x * NINV) for x in forward(r_)]
+                fd = forward(d_)
+                for k in range(N):
+                    acc[k] = track(acc[k] + modmul(fd[k], fr[k]))
+            out = inverse(acc)
+            e1 = negacyclic(digs[0], rows[0])
+            assert out == [6 * x for x in e1]
     print("ok: generator", g, "psi", PSI, "max |value| = 2^%.2f" % np.log2(stats["max_abs"]), "P/2 margin %.2f bits" % (np.log2(P / 2) - np.log2(max(abs(x) for x in exact))))
