@@ -82,6 +82,12 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch wheels bundle their own HIP runtime; two HIP runtimes in one process do not coexist (whichever loads
+        # second sees no device).  Loading torch's first lets librtfhe_hip.so bind to it, so both can be used together.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if build_if_missing:
         _build.build()
     if not os.path.exists(_build.LIB):

@@ -121,3 +121,27 @@ def test_degenerate_inputs(engine, orc, params, keys):
     # a bootstrap of a pre-combined TLWE equals the COPY gate
     t = keys.encrypt_bits([1])
     assert np.array_equal(engine.bootstrap_batch(t), engine.gate_batch(R.COPY, t))
+
+
+def test_config1_example_and_sharded_path_on_one_gpu(engine, params, keys):
+    """BASELINE config 1: the homnand-bench example counterpart runs its truth tables; and the scatter/compute/gather
+    helper of the multi-GPU path (rustfhe_amd/shard.py) with its real GPU callback at world size 1."""
+    import contextlib, io, os, runpy
+    import torch
+    import rustfhe_amd as R
+    from rustfhe_amd.shard import ShardedGates, engine_compute
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):      # in-process: a GPU-initialised process must not spawn GPU children here
+        runpy.run_path(os.path.join(root, "examples", "homnand_bench.py"), run_name="__main__")
+    text = buf.getvalue()
+    assert "all truth tables ok" in text, text[-2000:]
+    assert text.count("micro-seconds") == 18                 # the reference example's 18 bootstraps
+    rng = np.random.default_rng(91)
+    b0, b1 = rng.integers(0, 2, 700), rng.integers(0, 2, 700)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    sg = ShardedGates(engine_compute(engine), params.n + 1, torch.device("cuda", 0))
+    res = sg.run(R.NAND, torch.from_numpy(c0.view(np.int32)), torch.from_numpy(c1.view(np.int32)), 700)
+    got = res.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, engine.gate_batch(R.NAND, c0, c1))
+    assert keys.decrypt_bits(got) == list(1 - (b0 & b1))
