@@ -444,7 +444,7 @@ void orc_external_product(const orc_params *p, orc_plan *pl, const double *trgsw
 void orc_cmux(const orc_params *p, orc_plan *pl, const double *trgsw_f, const uint32_t *trgsw_t,
               const uint32_t *rep1, const uint32_t *rep0, uint32_t *out) {
     const int32_t N2 = 2 * p->N;
-    uint32_t *d = (uint32_t *)malloc(sizeof(uint32_t) * N2);
+    uint32_t *d = (uint32_t *)calloc((size_t)N2, sizeof(uint32_t));
     uint32_t *x = (uint32_t *)malloc(sizeof(uint32_t) * N2);
     for (int32_t k = 0; k < N2; k++) d[k] = rep1[k] - rep0[k];
     orc_external_product(p, pl, trgsw_f, trgsw_t, d, x);

@@ -85,17 +85,22 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
 #define WG_STAMP(k) do { } while (0)
 #endif
     const size_t trgsw_cplx = (size_t)ROWS * 2 * R * 64;
+    // BK values this wave needs in the M phase: point m = wave of every row and component (coalesced 1 KiB each).
+    // Software-pipelined: the values of step i + 1 are requested at the start of step i's I phase (6 of the 8 waves idle
+    // there) and have landed by the barrier that ends it.
+    cplx bkv[ROWS][2];
+    auto load_bk = [&](int step, cplx (&dst)[ROWS][2]) {
+        const cplx* bk_i = a.bk + (size_t)step * trgsw_cplx;
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+            dst[j][0] = bk_i[(size_t)((j * 2 + 0) * R + wave) * 64 + lane];
+            dst[j][1] = bk_i[(size_t)((j * 2 + 1) * R + wave) * 64 + lane];
+        }
+    };
+    if (a.steps > 0) load_bk(0, bkv);
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        const cplx* bk_i = a.bk + (size_t)i * trgsw_cplx;
-        // BK values this wave needs in the M phase: point m = wave of every row and component (coalesced 1 KiB each)
-        cplx bkv[ROWS][2];
-#pragma unroll
-        for (int j = 0; j < ROWS; j++) {
-            bkv[j][0] = bk_i[(size_t)((j * 2 + 0) * R + wave) * 64 + lane];
-            bkv[j][1] = bk_i[(size_t)((j * 2 + 1) * R + wave) * 64 + lane];
-        }
         WG_STAMP(0);
         // ---- F: one digit polynomial per wave (trgsw.rs:269-289) ----
         if (wave < ROWS) {
@@ -142,6 +147,8 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
         WG_STAMP(3);
         __syncthreads();
         WG_STAMP(4);
+        cplx bkn[ROWS][2];
+        load_bk(i + 1 < a.steps ? i + 1 : i, bkn);
         // ---- I: one accumulator component per wave (math.rs:279-288; trlwe.rs:49-60 for the += ) ----
         if (wave < 2) {
             double re[R], im[R];
@@ -160,6 +167,8 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
         WG_STAMP(5);
         __syncthreads();
         WG_STAMP(6);
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) { bkv[j][0] = bkn[j][0]; bkv[j][1] = bkn[j][1]; }
     }
 #ifdef RTFHE_WG_STAMPS
     if (a.dbg && blockIdx.x == 0 && lane == 0)
