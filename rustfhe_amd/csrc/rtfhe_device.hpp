@@ -208,7 +208,7 @@ struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uni
 // the later reads are still in flight (matters when one wave has the SIMD to itself).
 template <int LOGN, int FROM, int TO, bool DUAL = false>
 __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                         double* __restrict__ xbuf, int lane) {
+                                         double* __restrict__ xbuf, int lane, double* __restrict__ ximbuf = nullptr) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
     auto slot = [&](int layout, int m) {
@@ -217,7 +217,7 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
         return (FROM + TO == 3) ? G::f1(pos) : G::f2(pos);
     };
     if constexpr (DUAL) {
-        double* xim = xbuf + G::XSLOTS;
+        double* xim = ximbuf ? ximbuf : xbuf + G::XSLOTS;   // second buffer: caller's, or right behind the first
 #pragma unroll
         for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
 #pragma unroll
@@ -252,7 +252,8 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
 // tw: LDS, forward table.  xbuf: LDS, wave-private, Geo::XSLOTS doubles.
 template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                              const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+                                              const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
+                                              double* __restrict__ xim = nullptr) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
     Tw<R> wt; Tw<R - 1> w1, w2;
@@ -261,23 +262,25 @@ __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double
     twist_mul<R>(re, im, wt.w);
     P12<R, G::LR - 1>::fwd(re, im, w1.w);
     w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);     // in flight during the exchange
-    exchange<LOGN, 1, 2, DUAL>(re, im, xbuf, lane);
+    exchange<LOGN, 1, 2, DUAL>(re, im, xbuf, lane, xim);
     P12<R, G::LR - 1>::fwd(re, im, w2.w);
 }
 template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                              const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+                                              const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
+                                              double* __restrict__ xim = nullptr) {
     typedef Geo<LOGN> G;
     Tw<G::NLOW - 4> w3;
     w3.load(tw + G::TW_P3, 1);
-    exchange<LOGN, 2, 3, DUAL>(re, im, xbuf, lane);
+    exchange<LOGN, 2, 3, DUAL>(re, im, xbuf, lane, xim);
     P3<G::R, G::NLOW, G::LOW - 1>::fwd(re, im, w3.w);
 }
-template <int LOGN>
+template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                            const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane) {
-    fft_forward_a<LOGN>(re, im, tw, xbuf, lane);
-    fft_forward_b<LOGN>(re, im, tw, xbuf, lane);
+                                            const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
+                                            double* __restrict__ xim = nullptr) {
+    fft_forward_a<LOGN, DUAL>(re, im, tw, xbuf, lane, xim);
+    fft_forward_b<LOGN, DUAL>(re, im, tw, xbuf, lane, xim);
 }
 
 // Inverse transform.  in: layout L3, unscaled (the 2/N factor lives in the untwist twiddles).  out: layout L1, untwisted (natural
@@ -287,17 +290,17 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                             const cplx* __restrict__ tw_small, const cplx* __restrict__ tw_big,
-                                            double* __restrict__ xbuf, int lane) {
+                                            double* __restrict__ xbuf, int lane, double* __restrict__ xim = nullptr) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
     Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1; Tw<R> wt;
     w3.load(tw_small + G::TW_P3, 1);
     P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
     w2.load(tw_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
-    exchange<LOGN, 3, 2, DUAL>(re, im, xbuf, lane);
+    exchange<LOGN, 3, 2, DUAL>(re, im, xbuf, lane, xim);
     P12<R, G::LR - 1>::inv(re, im, w2.w);
     w1.load(tw_big + G::TW_P1 + lane, 64);          // in flight during the exchange
-    exchange<LOGN, 2, 1, DUAL>(re, im, xbuf, lane);
+    exchange<LOGN, 2, 1, DUAL>(re, im, xbuf, lane, xim);
     wt.load(tw_big + G::TW_TWIST + lane, 64);
     P12<R, G::LR - 1>::inv(re, im, w1.w);
     twist_mul<R>(re, im, wt.w);

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                 re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
                 im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
             }
-            fft_forward<LOGN>(re, im, twf, xbuf, lane);
+            // second exchange buffer = this wave's own (still unwritten) spectrum slot
+            fft_forward<LOGN, true>(re, im, twf, xbuf, lane, reinterpret_cast<double*>(spec + (size_t)wave * P));
             cplx* dst = spec + (size_t)wave * P + lane;
 #pragma unroll
             for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             const cplx* src = sbuf + (size_t)wave * P + lane;
 #pragma unroll
             for (int m = 0; m < R; m++) { const cplx v = src[m * 64]; re[m] = v.x; im[m] = v.y; }
-            fft_inverse<LOGN>(re, im, twi, twi, xbuf, lane);
+            // the spectra are dead after the M phase: slot `wave` serves as the second exchange buffer
+            fft_inverse<LOGN, true>(re, im, twi, twi, xbuf, lane, reinterpret_cast<double*>(spec + (size_t)wave * P));
             uint32_t* poly = accbuf + wave * N;
 #pragma unroll
             for (int m = 0; m < R; m++) {
