@@ -72,5 +72,10 @@ extern "C" {
     pub fn rtfhe_keygen_with_keys(p: *const rtfhe_params, seed: u64, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
     pub fn rtfhe_tlwe_encrypt_bits(p: *const rtfhe_params, key0: *const i32, seed: u64, bits: *const u8, out: *mut u32, count: usize) -> c_int;
     pub fn rtfhe_tlwe_decrypt_bits(p: *const rtfhe_params, key0: *const i32, input: *const u32, bits: *mut u8, count: usize) -> c_int;
+    pub fn rtfhe_keys_write(path: *const c_char, p: *const rtfhe_params, key0: *const i32, key1: *const i32, bk: *const u32, ksk: *const u32) -> c_int;
+    pub fn rtfhe_keys_read_header(path: *const c_char, p: *mut rtfhe_params, flags: *mut u32) -> c_int;
+    pub fn rtfhe_keys_read(path: *const c_char, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_tlwe_write(path: *const c_char, n: i32, cts: *const u32, count: usize) -> c_int;
+    pub fn rtfhe_tlwe_read(path: *const c_char, n: *mut i32, count: *mut u64, cts: *mut u32, capacity: usize) -> c_int;
     pub fn rtfhe_tlwe_phase(p: *const rtfhe_params, key0: *const i32, input: *const u32, phase: *mut u32, count: usize) -> c_int;
 }

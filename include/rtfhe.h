@@ -19,6 +19,7 @@
  *   rtfhe_key_switch_batch           <- TLWERep::identity_key_switch (hom_nand/src/tlwe.rs:43-73)
  *   rtfhe_ifft_i32_batch             <- Spqlios_ifft_i32 / _u32 (utils/src/spqlios.rs:22-23, spqlios-wrapper.cpp:22-28)
  *   rtfhe_fft_u32_batch              <- Spqlios_fft_u32 (utils/src/spqlios.rs:25, spqlios-wrapper.cpp:34-36)
+ *   rtfhe_keys_* / rtfhe_tlwe_write/read  (no reference counterpart: it has no serialization; fixes App. A's layouts into files)
  *   rtfhe_keygen / rtfhe_tlwe_*      <- TFHE::new, Cryptor::encrypto/decrypto(TLWE, ..) (tfhe.rs:21-25, tlwe.rs:213-241)
  *
  * Conventions: every call returns 0 on success or a negative rtfhe_status; nothing aborts or throws
@@ -144,6 +145,16 @@ int rtfhe_tlwe_encrypt_bits(const rtfhe_params *p, const int32_t *key0, uint64_t
 int rtfhe_tlwe_decrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint32_t *in,
                             uint8_t *bits, size_t count);
 int rtfhe_tlwe_phase(const rtfhe_params *p, const int32_t *key0, const uint32_t *in, uint32_t *phase, size_t count);
+
+/* ---- wire format (flat little-endian files with an FNV-1a checksum; the reference has no serialization) ----
+ * key file   "RTFHEKY1" | rtfhe_params | u32 flags (1 bk, 2 ksk, 4 secret keys) | u32 0 | [key0 | key1] | [bk] | [ksk] | u64 fnv
+ * batch file "RTFHECT1" | i32 n | i32 0 | u64 count | u32[count][n+1] | u64 fnv */
+int rtfhe_keys_write(const char *path, const rtfhe_params *p, const int32_t *key0, const int32_t *key1,
+                     const uint32_t *bk, const uint32_t *ksk);          /* null sections are left out */
+int rtfhe_keys_read_header(const char *path, rtfhe_params *p, uint32_t *flags);
+int rtfhe_keys_read(const char *path, int32_t *key0, int32_t *key1, uint32_t *bk, uint32_t *ksk);   /* null = skip */
+int rtfhe_tlwe_write(const char *path, int32_t n, const uint32_t *cts, size_t count);
+int rtfhe_tlwe_read(const char *path, int32_t *n, uint64_t *count, uint32_t *cts /* NULL: header only */, size_t capacity);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,11 @@ _SIGNATURES = {
     "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_tlwe_decrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_tlwe_phase": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_keys_write": (C.c_int, [C.c_char_p, "PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_keys_read_header": (C.c_int, [C.c_char_p, "PP", C.POINTER(C.c_uint32)]),
+    "rtfhe_keys_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_tlwe_write": (C.c_int, [C.c_char_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "rtfhe_tlwe_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import AND, ANDNY, COPY, NAND, NOT, OR, XOR, Params  # noqa: F401
+from ._ffi import AND, ANDNY, COPY, ERR_INVALID, NAND, NOT, OR, XOR, Params  # noqa: F401
 
 
 class RtfheError(RuntimeError):
@@ -223,3 +223,47 @@ def phases(params, key0, cts):
     if rc != 0:
         raise RtfheError(rc, "rtfhe_tlwe_phase failed")
     return ph
+
+
+# ---- wire format (flat files; include/rtfhe.h) ----------------------------------------------------
+
+def save_keys(path, params, key0=None, key1=None, bk=None, ksk=None):
+    L = _ffi.load()
+    arrs = [None if a is None else _np(a, dt) for a, dt in ((key0, np.int32), (key1, np.int32), (bk, np.uint32), (ksk, np.uint32))]
+    rc = L.rtfhe_keys_write(path.encode(), C.byref(params), *[_ptr(a) for a in arrs])
+    if rc != 0:
+        raise RtfheError(rc, "rtfhe_keys_write failed")
+
+
+def load_keys(path, want_bk=True, want_ksk=True):
+    """Returns (params, key0, key1, bk, ksk); sections absent from the file (or not wanted) come back as None."""
+    L = _ffi.load()
+    p, flags = Params(), C.c_uint32()
+    if L.rtfhe_keys_read_header(path.encode(), C.byref(p), C.byref(flags)) != 0:
+        raise RtfheError(ERR_INVALID, "not an rtfhe key file: " + path)
+    f = flags.value
+    key0 = np.empty(p.n, np.int32) if f & 4 else None
+    key1 = np.empty(p.N, np.int32) if f & 4 else None
+    bk = np.empty(p.bk_words, np.uint32) if (f & 1 and want_bk) else None
+    ksk = np.empty(p.ksk_words, np.uint32) if (f & 2 and want_ksk) else None
+    if L.rtfhe_keys_read(path.encode(), _ptr(key0), _ptr(key1), _ptr(bk), _ptr(ksk)) != 0:
+        raise RtfheError(ERR_INVALID, "corrupt rtfhe key file (checksum or length): " + path)
+    return p, key0, key1, bk, ksk
+
+
+def save_tlwe(path, params, cts):
+    L = _ffi.load()
+    cts = _np(cts, np.uint32).reshape(-1, params.n + 1)
+    if L.rtfhe_tlwe_write(path.encode(), params.n, _ptr(cts), cts.shape[0]) != 0:
+        raise RtfheError(ERR_INVALID, "rtfhe_tlwe_write failed")
+
+
+def load_tlwe(path):
+    L = _ffi.load()
+    n, count = C.c_int32(), C.c_uint64()
+    if L.rtfhe_tlwe_read(path.encode(), C.byref(n), C.byref(count), None, 0) != 0:
+        raise RtfheError(ERR_INVALID, "not an rtfhe ciphertext file: " + path)
+    out = np.empty((count.value, n.value + 1), np.uint32)
+    if L.rtfhe_tlwe_read(path.encode(), C.byref(n), C.byref(count), _ptr(out), count.value) != 0:
+        raise RtfheError(ERR_INVALID, "corrupt rtfhe ciphertext file: " + path)
+    return out

@@ -112,3 +112,38 @@ def test_rust_sys_crate_declares_the_same_abi():
     assert declared == rust, declared ^ rust
     fields = re.findall(r"pub (\w+): i32", rs.split("pub struct rtfhe_params")[1].split("}")[0])
     assert fields == ["n", "N", "nbit", "l", "bgbit", "ks_t", "ks_basebit"]
+
+
+def test_wire_format_roundtrip_and_corruption(tmp_path):
+    import rustfhe_amd as R
+    p = R.Params(n=12)
+    key0, key1, bk, ksk = R.keygen(p, 77)
+    path = str(tmp_path / "keys.rtfhe")
+    R.save_keys(path, p, key0, key1, bk, ksk)
+    assert os.path.getsize(path) == 8 + 28 + 8 + 4 * (p.n + p.N) + 4 * (p.bk_words + p.ksk_words) + 8
+    q, k0, k1, b2, s2 = R.load_keys(path)
+    assert (q.n, q.N, q.l, q.bgbit, q.ks_t, q.ks_basebit, q.nbit) == (12, 1024, 3, 6, 8, 2, 10)
+    assert np.array_equal(k0, key0) and np.array_equal(k1, key1) and np.array_equal(b2, bk) and np.array_equal(s2, ksk)
+    # public part only (what a server would hold): no secret keys in the file
+    pub = str(tmp_path / "pub.rtfhe")
+    R.save_keys(pub, p, None, None, bk, ksk)
+    q, k0, k1, b2, s2 = R.load_keys(pub, want_ksk=False)
+    assert k0 is None and k1 is None and s2 is None and np.array_equal(b2, bk)
+    # ciphertext batches, including the empty one
+    cts = R.encrypt_bits(p, key0, [1, 0, 1], 5)
+    cpath = str(tmp_path / "batch.rtfhe")
+    R.save_tlwe(cpath, p, cts)
+    assert np.array_equal(R.load_tlwe(cpath), cts)
+    R.save_tlwe(cpath, p, cts[:0])
+    assert R.load_tlwe(cpath).shape == (0, p.n + 1)
+    # corruption and truncation are detected
+    raw = bytearray(open(path, "rb").read())
+    raw[200] ^= 1
+    open(path, "wb").write(raw)
+    with pytest.raises(R.RtfheError):
+        R.load_keys(path)
+    open(path, "wb").write(raw[:1000])
+    with pytest.raises(R.RtfheError):
+        R.load_keys(path)
+    with pytest.raises(R.RtfheError):
+        R.load_tlwe(pub)
