@@ -553,10 +553,18 @@ typedef struct {
     const uint32_t *in0, *in1; uint32_t *out; size_t begin, end;
 } mt_job;
 
+/* optional: every worker thread gets its own handle of an external transform (the reference's Spqlios_new /
+ * Spqlios_ifft_i32 / Spqlios_fft_u32 from oracle/_ref), as the reference's thread_local FFT_MAP would (math.rs:349-360) */
+static void *(*g_mt_new)(int32_t) = NULL;
+static orc_fwd_hook g_mt_fwd = NULL;
+static orc_inv_hook g_mt_inv = NULL;
+void orc_set_mt_hooks(void *(*new_fn)(int32_t), orc_fwd_hook fwd, orc_inv_hook inv) { g_mt_new = new_fn; g_mt_fwd = fwd; g_mt_inv = inv; }
+
 static void *mt_worker(void *arg) {
     mt_job *j = (mt_job *)arg;
     orc_plan *pl = orc_plan_new(j->p->N);
     orc_plan_set_backend(pl, j->backend);
+    if (j->backend == ORC_BACKEND_HOOK && g_mt_new) orc_plan_set_hooks(pl, g_mt_new(j->p->N), g_mt_fwd, g_mt_inv);
     const size_t w = (size_t)j->p->n + 1;
     for (size_t g = j->begin; g < j->end; g++)
         orc_gate(j->p, pl, j->op, j->bk_f, j->bk_t, j->ksk, j->in0 + g * w, j->in1 ? j->in1 + g * w : NULL, j->out + g * w);

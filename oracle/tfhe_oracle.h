@@ -124,6 +124,7 @@ void orc_mux(const orc_params *p, orc_plan *pl, const double *bk_f, const uint32
              const uint32_t *ksk, const uint32_t *c, const uint32_t *in0, const uint32_t *in1, uint32_t *out);
 /* nthreads independent gate streams, each with its own plan (the reference's thread model
  * would be thread_local! FFT_MAP, math.rs:349-351).  Returns wall seconds. */
+void orc_set_mt_hooks(void *(*new_fn)(int32_t), orc_fwd_hook fwd, orc_inv_hook inv);   /* backend ORC_BACKEND_HOOK in the call below */
 double orc_gate_batch_mt(const orc_params *p, int backend, int op, const double *bk_f, const uint32_t *bk_t,
                          const uint32_t *ksk, const uint32_t *in0, const uint32_t *in1, uint32_t *out,
                          size_t count, int nthreads);

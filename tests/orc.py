@@ -99,6 +99,7 @@ def lib():
         "orc_gate": (None, [PP, vp, C.c_int, f64p, u32p, u32p, u32p, u32p, u32p]),
         "orc_mux": (None, [PP, vp, f64p, u32p, u32p, u32p, u32p, u32p, u32p]),
         "orc_gate_batch_mt": (C.c_double, [PP, C.c_int, C.c_int, f64p, u32p, u32p, u32p, u32p, u32p, C.c_size_t, C.c_int]),
+        "orc_set_mt_hooks": (None, [vp, vp, vp]),
         "orc_rng_seed": (None, [C.POINTER(Rng), C.c_uint64]),
         "orc_rng_next": (C.c_uint64, [C.POINTER(Rng)]),
         "orc_rng_uniform_torus": (u32, [C.POINTER(Rng)]),
@@ -347,6 +348,18 @@ def gate_batch_mt(params, op, bk_f, bk_t, ksk, in0, in1, nthreads, backend=BACKE
                                    _p(ksk, C.c_uint32), _p(in0, C.c_uint32), _p(in1, C.c_uint32),
                                    _p(out, C.c_uint32), in0.shape[0], nthreads)
     return out, secs
+
+
+_mt_ref = None
+
+
+def use_reference_fft_in_mt():
+    """Worker threads of gate_batch_mt(backend=BACKEND_HOOK) each get their own handle of the reference's compiled spqlios."""
+    global _mt_ref
+    if _mt_ref is None:
+        R = ref_lib()
+        lib().orc_set_mt_hooks(C.cast(R.Spqlios_new, C.c_void_p), C.cast(R.Spqlios_ifft_i32, C.c_void_p), C.cast(R.Spqlios_fft_u32, C.c_void_p))
+        _mt_ref = R
 
 
 def fnv64(arr):
