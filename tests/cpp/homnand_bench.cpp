@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <random>
 
-#include "../../rustfhe_amd/host/hom_nand.hpp"
+#include "../../rustfhe_amd/host/hom_nand_ring.hpp"
 
 using namespace hom_nand;
 
@@ -47,6 +47,30 @@ int main() {
         for (int i = 0; i < 6; i++) { va.push_back(enc((i & 1) ? Binary::One : Binary::Zero)); vb.push_back(enc((i & 2) ? Binary::One : Binary::Zero)); }
         auto vr = tfhe.hom_nand_batch(va, vb);
         for (int i = 0; i < 6; i++) if (!(vr[i] == tfhe.hom_nand(va[i], vb[i]))) { std::printf("batch != single at %d\n", i); bad++; }
+        // ring-level surface: rotate KATs (utils/src/math.rs:75-84 on N = 8 analogue), TRLWE -> sample extract, TRGSW cmux
+        {
+            Polynomial<8> q; for (int i = 0; i < 8; i++) q[i] = (uint32_t)(i + 1);
+            const Polynomial<8> r1 = q.rotate(1), rm1 = q.rotate(-1), r8 = q.rotate(8), r16 = q.rotate(16);
+            if (r1[0] != (uint32_t)-8 || r1[1] != 1 || rm1[7] != (uint32_t)-1 || rm1[0] != 2 || r8[3] != (uint32_t)-4 || !(r16 == q)) { std::printf("rotate WRONG\n"); bad++; }
+            Polynomial<TRLWE_N> m1, m0;
+            for (int k = 0; k < TRLWE_N; k++) { m1[k] = 0x20000000u; m0[k] = 0xE0000000u; }
+            auto rep1 = trlwe_encrypto<TRLWE_N>(s1, m1, 501), rep0 = trlwe_encrypto<TRLWE_N>(s1, m0, 502);
+            auto t1 = rep1.sample_extract_index(0);
+            if ((int)Cryptor::decrypto<TRLWE_N>(TLWE{}, s1, t1) != 1) { std::printf("sample_extract WRONG\n"); bad++; }
+            for (int bit = 0; bit < 2; bit++) {
+                TRGSWRepF<TRLWE_N> c(TRGSWRep<TRLWE_N>::encrypto(s1, bit ? Binary::One : Binary::Zero, 600 + bit));
+                auto sel = c.cmux(rep1, rep0);                                   // TRGSW(i).cmux(rep_1, rep_0) = rep_i
+                auto ph = trlwe_decrypto<TRLWE_N>(s1, sel);
+                int wrong = 0;
+                for (int k = 0; k < TRLWE_N; k++) if ((int)TLWEHelper::torus2binary(ph[k]) != bit) wrong++;
+                if (wrong) { std::printf("cmux(%d) WRONG in %d coefficients\n", bit, wrong); bad++; }
+            }
+            KeySwitchingKey<TRLWE_N, TLWE_N> ksk(s1, s0, 7);
+            auto row = ksk.get(3, 0, 1);                                         // TLWE(1 * s1[3] / 4)
+            Torus32 s = 0; for (int i = 0; i < TLWE_N; i++) if (s0[i] == Binary::One) s += row.p_key()[i];
+            const int32_t err = (int32_t)(row.cipher() - s - (s1[3] == Binary::One ? 0x40000000u : 0u));
+            if (err > (1 << 21) || err < -(1 << 21)) { std::printf("KeySwitchingKey::get WRONG\n"); bad++; }
+        }
         std::printf(bad ? "FAILED %d\n" : "all truth tables ok\n", bad);
         return bad ? 1 : 0;
     } catch (const std::exception& e) {
