@@ -159,6 +159,15 @@ def main():
                          "kernel": "k_bootstrap" if args.backend == "fft64-mirror" else "k_bootstrap_ntt", "avg_launch_ms": round(1e3 * launch_s, 3),
                          "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G},
         }
+        if args.backend == "fft64-mirror" and G <= 1024:
+            # what actually binds the kernel: FP64 issue.  The mirror arithmetic may not fuse multiply-add, a
+            # gate costs 3,808 FP64 wave-instructions per CMUX, and one wave per SIMD issues one every 6.75 cycles
+            # (scripts/ubench/fp64_issue.hip, profiles/ubench/fp64_lds_issue_rates.log); clock from GRBM_GUI_ACTIVE (2.36 GHz)
+            dp_ops, cyc, clk = 3808 * params.n, 6.75, 2.36e9
+            floor_s = dp_ops * cyc / clk * ((G + 1023) // 1024)
+            line["fp64_issue_roofline"] = {"bound": "fp64 issue, one wave per SIMD, no FMA", "dp_wave_instr_per_gate": dp_ops,
+                                           "cycles_per_instr": cyc, "clock_hz": clk, "floor_ms_per_launch": round(1e3 * floor_s, 3),
+                                           "frac": round(floor_s / launch_s, 4)}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
