@@ -13,6 +13,7 @@
 
 #include "rtfhe_kernels.hpp"
 #include "rtfhe_kernels_wg.hpp"
+#include "rtfhe_kernels_pair.hpp"
 #include "rtfhe_kernels_ntt.hpp"
 
 using namespace rtfhe;
@@ -173,7 +174,7 @@ struct rtfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
-    unsigned long long* d_dbg = nullptr;   // RTFHE_WG_STAMPS builds: 64 words of phase timings
+    unsigned long long* d_dbg = nullptr;   // RTFHE_WG_STAMPS builds: 128 words of phase timings
     int num_cus = 256;
     int force_waves = 0;   // RTFHE_FORCE_WAVES=1|4|8 (tuning knob: 1 = workgroup-per-gate kernel)
     int wg_max = 512;      // RTFHE_WG_MAX_GATES: largest batch routed to the workgroup-per-gate kernel
@@ -239,6 +240,17 @@ int launch_bootstrap_wg10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return 0;
 }
 
+int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    constexpr int GATES = 4;
+    auto k = k_bootstrap_pair<3, 6, 8, 2, KSQ, GATES>;
+    const size_t lds = PairLds::bytes(GATES, a.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3((a.count + GATES - 1) / GATES), dim3(128 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
 // Kernel shape by batch size (N = 1024):
 //   count <= wg_max (default 2 gates per CU) : one gate per 8-wave workgroup (k_bootstrap_wg): ~3.5x lower latency
 //   count <= 4 gates per CU                  : one gate per wave, 4-wave workgroups, every CU busy
@@ -248,6 +260,7 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     if constexpr (LOGN == 10) {
         const int force = ctx->force_waves;
         if (force == 1 || (force == 0 && a.count <= ctx->wg_max)) return launch_bootstrap_wg10(ctx, a, s);
+        if (force == 2) return launch_bootstrap_pair10(ctx, a, s);
         if (force == 8 || (force == 0 && a.count > 4 * ctx->num_cus)) return launch_bootstrap_w<10, 8>(ctx, a, s);
         return launch_bootstrap_w<10, 4>(ctx, a, s);
     } else {
@@ -457,16 +470,16 @@ int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
         rc = fail(ctx, RTFHE_ERR_HIP, "hipEventCreate failed");
     if (rc) { g_last_error = ctx->err; rtfhe_ctx_destroy(ctx); return rc; }
 #ifdef RTFHE_WG_STAMPS
-    if (hipMalloc((void**)&ctx->d_dbg, 64 * 8) == hipSuccess) (void)hipMemset(ctx->d_dbg, 0, 64 * 8);
+    if (hipMalloc((void**)&ctx->d_dbg, 128 * 8) == hipSuccess) (void)hipMemset(ctx->d_dbg, 0, 128 * 8);
 #endif
     *out = ctx;
     return 0;
 }
 
 #ifdef RTFHE_WG_STAMPS
-extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out64) {
+extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out128) {
     if (!ctx || !ctx->d_dbg) return RTFHE_ERR_STATE;
-    return hipMemcpy(out64, ctx->d_dbg, 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : RTFHE_ERR_HIP;
+    return hipMemcpy(out128, ctx->d_dbg, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : RTFHE_ERR_HIP;
 }
 #endif
 

@@ -1,0 +1,296 @@
+// rtfhe_kernels_pair.hpp -- the bootstrap kernel with TWO WAVES PER GATE (N = 1024).
+//
+// k_bootstrap gives a gate one wavefront.  A launch with at most one gate per SIMD (the headline batch: 1024 gates on
+// 1024 SIMDs) then leaves every SIMD with a single resident wave, and a lone wave issues one FP64 instruction per
+// ~6.75 cycles where two waves sharing the SIMD reach one per ~5.4 (profiles/ubench).  Here the two waves of a pair split
+// one gate's CMUX step; the arithmetic and its order are unchanged (see cmux_step for the reference citations):
+//
+//   wave 0 ("b side")                               wave 1 ("a side")
+//   decompose b-poly, transforms of rows 0..2       decompose a-poly, transforms of rows 3..5        (spectra stay in VGPRs)
+//   s0 = 0 + rows 0..2 of component 0  -> LDS
+//   ------------------------------------------ barrier -----------------------------------------------
+//   s1 = 0 + rows 0..2 of component 1  -> LDS       s0 += rows 3..5 of component 0 -> LDS
+//   ------------------------------------------ barrier -----------------------------------------------
+//   inverse transform of s0, += into the b-poly     s1 += rows 3..5 of component 1; inverse, += into the a-poly
+//
+// The fold order of every accumulator point is rows 0, 1, ..., 5 from +0.0, exactly as in the reference
+// (trgsw.rs:290-299): the partial sums travel, the products are never re-associated.  Each wave only ever touches its
+// own accumulator polynomial, so two barriers per step suffice.  Hand-off buffers are the (idle) exchange buffers:
+// partial s0 and final s0 through wave 0's, partial s1 through wave 1's -- each is written only while its owner is
+// between transforms, in program order with the barriers.
+#pragma once
+
+#include "rtfhe_kernels.hpp"
+
+namespace rtfhe {
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
+// spaces, i.e. s_waitcnt vmcnt(0): it would wait for the key rows prefetched across it.  Hand-offs here go through LDS.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef PAIR_SYNCTHREADS
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <int R>
+__device__ __forceinline__ void mac_row(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
+    // hadamard + fold-add, utils/src/spqlios.rs:204-222, hom_nand/src/trgsw.rs:290-299 (same operation order as cmux_step)
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const double ii = b[m].y * im[m], rr = b[m].x * re[m], ri = b[m].x * im[m], ir = b[m].y * re[m];
+        sre[m] = sre[m] + (rr - ii);
+        sim[m] = sim[m] + (ir + ri);
+    }
+}
+
+struct PairLds {
+    typedef Geo<10> G;
+    static constexpr size_t TW = (size_t)G::TW_TOTAL * sizeof(cplx);
+    static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers
+    static_assert(XB >= (size_t)G::P * sizeof(cplx), "an exchange buffer pair must hold one spectrum");
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * G::N * 4 + (size_t)npad * 4 + 2 * XB; }
+    __host__ __device__ static constexpr size_t prog_offset(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return prog_offset(gates, npad) + 64; }   // + progress words
+};
+
+// GATES gates per workgroup, 2 * GATES waves: wave w serves gate (w % GATES) as side (w / GATES)
+template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
+__global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const BootstrapArgs a) {
+    constexpr int LOGN = 10;
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, P = G::P, R = G::R, NT = 128 * GATES;
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    static_assert(L == 3, "three rows per side are held in registers");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave % GATES, side = wave / GATES;
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    for (int idx = tid; idx < G::TW_TOTAL; idx += NT) tw[idx] = a.tw[idx];
+    volatile int* prog = reinterpret_cast<volatile int*>(smem + PairLds::prog_offset(GATES, a.npad));   // see `pace`
+    if (tid < 2 * GATES) prog[tid] = 0;
+    const cplx* twf = tw;
+    const cplx* twi = tw + G::TW_DIR;
+
+    // idle pairs of the last workgroup shadow the last gate (they take part in every barrier) and store nothing
+    const int g_raw = blockIdx.x * GATES + slot;
+    const bool live = g_raw < a.count;
+    const int g = live ? g_raw : a.count - 1;
+
+    unsigned char* gbase = smem + PairLds::TW + (size_t)slot * PairLds::gate_bytes(a.npad);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);
+    uint32_t* abar = accbuf + 2 * N;
+    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + (size_t)a.npad * 4);
+    double* xb1 = xb0 + 2 * G::XSLOTS;
+    double* myx = side ? xb1 : xb0;
+    cplx* hand0 = reinterpret_cast<cplx*>(xb0) + lane;    // [R][64] cplx
+    cplx* hand1 = reinterpret_cast<cplx*>(xb1) + lane;
+    uint32_t* poly = accbuf + side * N;
+
+    const int n = a.n;
+    {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108)
+        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
+        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
+        const int op = a.ops ? a.ops[g] : a.op;
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane + 64 * side; i <= n; i += 128) {
+            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
+        }
+    }
+    __syncthreads();
+    {   // acc = X^{-bbar} * testvec (tfhe.rs:85, 98-106): side 0 holds the b-poly, side 1 the (zero) a-poly
+        const int bbar = (int)abar[n];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = lane + 64 * mm;
+            const int e = (c + bbar) & (2 * N - 1);
+            poly[c] = side ? 0u : ((e >> LOGN) ? 0xE0000000u : 0x20000000u);
+        }
+    }
+    wave_lds_sync();
+
+#ifdef RTFHE_WG_STAMPS
+    unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define PAIR_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[k] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PAIR_STAMP(k) do { } while (0)
+#endif
+    // Pacing.  The SIMD's arbiter is strictly priority-then-age ordered: of two waves that both have work, one runs at
+    // full speed and the other gets the leftovers (~1/3 speed), so the favoured wave of a pair reaches every barrier
+    // early and the SIMD then runs a single wave.  Each wave publishes its progress (in units of equal work) at every
+    // half-transform and raises its priority when it is behind its partner, lowers it when ahead: both sides then
+    // reach the barriers together.
+    const int partner = side ? slot : slot + GATES;
+    auto pace = [&](int p) {
+#ifdef PAIR_PACE
+        prog[wave] = p;                      // every lane stores the same word: no divergent branch
+        const int other = __builtin_amdgcn_readfirstlane(prog[partner]);
+        // one opaque statement, no compiler-visible control flow (extra basic blocks inside the transforms cost spills)
+        asm volatile("s_cmp_lt_i32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 2f\n1:\n\ts_setprio 3\n2:"
+                     :: "s"(p), "s"(other) : "scc");
+#endif
+    };
+    const size_t trgsw_cplx = (size_t)2 * L * 2 * R * 64;
+    // Key rows in consumption order rc = 0..5: (row rc % 3, component rc / 3) of this side.  A ring of two 8-point buffers
+    // runs across steps: each is refilled right after its multiply-accumulate retires, two MACs ahead of its use, the
+    // last two refills of a step fetching rows 0, 1 of the next one.
+    cplx bA[R], bB[R];
+    auto fetch = [&](cplx (&dst)[R], int step, int rc) {
+        const cplx* src = a.bk + (size_t)step * trgsw_cplx + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + lane;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < R; m++) dst[m] = src[m * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (a.steps > 0) {   // side 0 starts its ring with (bB, bA), side 1 with (bA, bB)
+        fetch(bA, 0, side ? 0 : 1);
+        fetch(bB, 0, side ? 1 : 0);
+    }
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        const int nxt = (i + 1 < a.steps) ? i + 1 : i;
+        // an opaque copy of the lane id per step: without it the compiler hoists every lane-derived LDS address out of
+        // the loop and then spills them (each is one VALU op to recompute)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        uint32_t u[2 * R];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = ln + 64 * mm;
+            const uint32_t own = poly[c];
+            u[mm] = ((rotated_coef<LOGN>(poly, c, r) - own) + M) ^ M;
+        }
+        PAIR_STAMP(0);
+        double xr[L][R], xi[L][R];
+#pragma unroll
+        for (int jj = 0; jj < L; jj++) {
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                xr[jj][m] = (double)decomp_digit(u[m], BGBIT, jj);
+                xi[jj][m] = (double)decomp_digit(u[R + m], BGBIT, jj);
+            }
+            fft_forward_a<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
+            pace(20 * i + (side ? 8 : 6) + 4 * jj);
+            fft_forward_b<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
+            pace(20 * i + (side ? 10 : 8) + 4 * jj);
+            PAIR_STAMP(1 + jj);
+        }
+
+        double sre[R], sim[R];
+        auto zero = [&]() {
+#pragma unroll
+            for (int m = 0; m < R; m++) { sre[m] = 0.0; sim[m] = 0.0; }
+        };
+        auto put = [&](cplx* h) {
+#pragma unroll
+            for (int m = 0; m < R; m++) h[m * 64] = make_double2(sre[m], sim[m]);
+        };
+        auto get = [&](const cplx* h) {
+#pragma unroll
+            for (int m = 0; m < R; m++) { const cplx v = h[m * 64]; sre[m] = v.x; sim[m] = v.y; }
+        };
+
+        // slot P (side 0): component 0 over rows 0..2 from +0.0
+        if (side == 0) {
+            zero();
+            mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
+            mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, i, 3);
+            mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, i, 4);
+            put(hand0);
+        }
+        pace(20 * i + 18);
+        PAIR_STAMP(4);
+        lds_barrier();
+        PAIR_STAMP(5);
+        // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
+        // on top of side 0's partial sum -> hand0
+        if (side == 0) zero(); else get(hand0);
+        mac_row<R>(sre, sim, bA, xr[0], xi[0]); fetch(bA, i, side ? 2 : 5);
+        mac_row<R>(sre, sim, bB, xr[1], xi[1]); fetch(bB, side ? i : nxt, side ? 3 : 0);
+        mac_row<R>(sre, sim, bA, xr[2], xi[2]); fetch(bA, side ? i : nxt, side ? 4 : 1);
+        put(side ? hand0 : hand1);
+        pace(20 * i + 20);
+        PAIR_STAMP(6);
+        lds_barrier();
+        PAIR_STAMP(7);
+        // slot R (side 1): component 1 over rows 3..5 on top of side 0's partial sum; side 0 picks up the finished s0
+        if (side == 1) {
+            get(hand1);
+            mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 5);
+            mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, nxt, 0);
+            mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, nxt, 1);
+            pace(20 * i + 22);
+        } else {
+            get(hand0);
+        }
+        PAIR_STAMP(8);
+
+        // the 2/N input scaling of the reference (fft_processor_spqlios.cpp:158) is folded into the untwist twiddles
+        fft_inverse<LOGN, true>(sre, sim, twi, twi, myx, lane);
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            poly[c] += trunc_to_torus(sre[m]);
+            poly[c + P] += trunc_to_torus(sim[m]);
+        }
+        wave_lds_sync();
+        pace(20 * i + (side ? 26 : 24));
+        PAIR_STAMP(9);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#ifdef RTFHE_WG_STAMPS
+    if (a.dbg && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; k++) a.dbg[wave * 16 + k] = tsum[k];
+#endif
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        if (live) {
+            uint32_t* o = a.out + (size_t)g * 2 * N + side * N;
+            for (int c = lane; c < N; c += 64) o[c] = poly[c];
+        }
+        return;
+    }
+
+    // sample extract index 0 (trlwe.rs:110-121): a'_0 = a_0, a'_k = -a_{N-k}; b' = b_0.  Side 1 owns the a-poly.
+    if (side == 1) {
+        uint32_t av[2 * R];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) av[mm] = poly[lane + 64 * mm];
+        wave_lds_sync();
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = lane + 64 * mm;
+            poly[(N - c) & (N - 1)] = (c == 0) ? av[mm] : (0u - av[mm]);
+        }
+    }
+    __syncthreads();
+    // identity key switch (tlwe.rs:43-73): each side sums the rows of half of the coefficients
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, side * (N / 2), (side + 1) * (N / 2), a.ksk, a.ksw, sum, lane);
+    uint4* part = reinterpret_cast<uint4*>(xb1) + lane;   // [KSQ][64] uint4
+    if (side == 1) {
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) part[q * 64] = sum[q];
+    }
+    __syncthreads();
+    if (side == 0 && live) {
+        const uint32_t bprime = accbuf[0];
+        uint32_t* out = a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1);
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) {
+            const uint4 o = part[q * 64];
+            const int col = 4 * (lane + 64 * q);
+            const uint32_t s[4] = {sum[q].x + o.x, sum[q].y + o.y, sum[q].z + o.z, sum[q].w + o.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (col + e <= n) out[col + e] = ((col + e == n) ? bprime : 0u) - s[e];
+        }
+    }
+}
+
+}  // namespace rtfhe

@@ -18,10 +18,10 @@ c = R.encrypt_bits(P, key0, [1, 0], 3)
 for count in (1, 256):
     cc = np.repeat(c[:1], count, axis=0)
     e.gate_batch(R.NAND, cc, cc)
-    out = (C.c_ulonglong * 64)()
+    out = (C.c_ulonglong * 128)()
     e.L.rtfhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
     assert e.L.rtfhe_debug_read_stamps(e.h, out) == 0
-    a = np.array(out[:], np.float64).reshape(8, 8) / 635.0
+    a = np.array(out[:64], np.float64).reshape(8, 8) / 635.0
     print("count", count, "cycles per step by phase (rows = waves 0..7; cols = head, F, bar, M, bar, I, bar, -)")
     np.set_printoptions(linewidth=200, suppress=True)
     print(np.round(a[:, :7]).astype(int))

@@ -188,7 +188,7 @@ def test_error_paths(engine, params):
     fresh.close()
 
 
-@pytest.mark.parametrize("force", ["1", "4", "8"])
+@pytest.mark.parametrize("force", ["1", "2", "4", "8"])
 def test_all_kernel_shapes_match_golden(params, keys, gold_gate, force, monkeypatch):
     """The three launch shapes (workgroup-per-gate, 4-wave and 8-wave wave-per-gate) are the same arithmetic:
     each one, forced through RTFHE_FORCE_WAVES, reproduces the golden gates bit for bit."""
