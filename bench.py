@@ -143,7 +143,7 @@ def main():
 
     if rank == 0:
         value = world * G * args.steps / elapsed
-        launch_s = kern_ms * 1e-3 / max(1, launches)
+        launch_s = kern_ms * 1e-3 / args.steps          # one batch; whole rounds of 4 gates per CU are ONE kernel launch
         achieved = ALG_BYTES_PER_GATE * G / launch_s
         line = {
             "metric": "HomNAND gates/sec (whole node), N=1024", "value": round(value, 1), "unit": "gates/s",
@@ -156,16 +156,17 @@ def main():
             "outputs_decrypt_correctly": ok and bad == 0.0,
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-                         "kernel": "k_bootstrap" if args.backend == "fft64-mirror" else "k_bootstrap_ntt", "avg_launch_ms": round(1e3 * launch_s, 3),
-                         "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G},
+                         "kernel": "k_bootstrap_pair" if args.backend == "fft64-mirror" else "k_bootstrap_ntt", "avg_launch_ms": round(1e3 * launch_s, 3),
+                         "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G, "launches_per_batch": round(launches / args.steps, 2)},
         }
-        if args.backend == "fft64-mirror" and G <= 1024:
+        if args.backend == "fft64-mirror" and G % 1024 == 0:
             # what actually binds the kernel: FP64 issue.  The mirror arithmetic may not fuse multiply-add, a
-            # gate costs 3,808 FP64 wave-instructions per CMUX, and one wave per SIMD issues one every 6.75 cycles
-            # (scripts/ubench/fp64_issue.hip, profiles/ubench/fp64_lds_issue_rates.log); clock from GRBM_GUI_ACTIVE (2.36 GHz)
-            dp_ops, cyc, clk = 3808 * params.n, 6.75, 2.36e9
-            floor_s = dp_ops * cyc / clk * ((G + 1023) // 1024)
-            line["fp64_issue_roofline"] = {"bound": "fp64 issue, one wave per SIMD, no FMA", "dp_wave_instr_per_gate": dp_ops,
+            # gate costs 3,808 FP64 wave-instructions per CMUX, and the two waves a SIMD holds (LDS and VGPR budget) issue
+            # one every 5.4 cycles together (scripts/ubench/fp64_issue.hip, profiles/ubench/fp64_lds_issue_rates.log);
+            # clock from GRBM_GUI_ACTIVE (2.36 GHz).  One gate per SIMD per round of 1024 gates.
+            dp_ops, cyc, clk = 3808 * params.n, 5.4, 2.36e9
+            floor_s = dp_ops * cyc / clk * (G // 1024)
+            line["fp64_issue_roofline"] = {"bound": "fp64 issue, two waves per SIMD, no FMA", "dp_wave_instr_per_gate": dp_ops,
                                            "cycles_per_instr": cyc, "clock_hz": clk, "floor_ms_per_launch": round(1e3 * floor_s, 3),
                                            "frac": round(floor_s / launch_s, 4)}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

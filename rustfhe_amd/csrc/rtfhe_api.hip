@@ -251,18 +251,38 @@ int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return 0;
 }
 
-// Kernel shape by batch size (N = 1024):
-//   count <= wg_max (default 2 gates per CU) : one gate per 8-wave workgroup (k_bootstrap_wg): ~3.5x lower latency
-//   count <= 4 gates per CU                  : one gate per wave, 4-wave workgroups, every CU busy
-//   larger                                   : one gate per wave, 8-wave workgroups (2 waves per SIMD)
+// `cnt` gates of a batch starting at gate `off` (plain batches advance the ciphertext pointers, netlist waves the index arrays)
+BootstrapArgs batch_segment(BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
+    if (a.idx0) { a.ops += off; a.idx0 += off; a.idx1 += off; a.idx_out += off; }
+    else { a.in0 += off * ((size_t)a.n + 1); a.in1 += off * ((size_t)a.n + 1); a.out += off * out_words; }
+    a.count = (int32_t)cnt;
+    return a;
+}
+
+// Kernel shape by batch size (N = 1024), measured in profiles/r01_pair/shape_sweep.log:
+//   whole rounds of 4 gates per CU : two waves per gate, 8-wave workgroups (k_bootstrap_pair) -- best throughput at every size
+//   a remainder <= wg_max (2 gates per CU) : one gate per 8-wave workgroup (k_bootstrap_wg): ~2.3x lower latency
+//   a larger remainder             : one more (partly filled) two-waves-per-gate round
+// The segments are queued back to back on the caller's stream.  RTFHE_FORCE_WAVES=1|2|4|8 forces one shape for the
+// whole batch (4, 8: one gate per wave in 4- / 8-wave workgroups).
 template <int LOGN>
 int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     if constexpr (LOGN == 10) {
         const int force = ctx->force_waves;
-        if (force == 1 || (force == 0 && a.count <= ctx->wg_max)) return launch_bootstrap_wg10(ctx, a, s);
+        if (force == 1) return launch_bootstrap_wg10(ctx, a, s);
         if (force == 2) return launch_bootstrap_pair10(ctx, a, s);
-        if (force == 8 || (force == 0 && a.count > 4 * ctx->num_cus)) return launch_bootstrap_w<10, 8>(ctx, a, s);
-        return launch_bootstrap_w<10, 4>(ctx, a, s);
+        if (force == 8) return launch_bootstrap_w<10, 8>(ctx, a, s);
+        if (force == 4) return launch_bootstrap_w<10, 4>(ctx, a, s);
+        const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * (1 << LOGN) : (size_t)a.n + 1;
+        const size_t round = (size_t)4 * ctx->num_cus, count = (size_t)a.count;
+        const size_t full = count / round * round, rem = count - full;
+        if (full)
+            if (int rc = launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (rem) {
+            const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+            return rem <= (size_t)ctx->wg_max ? launch_bootstrap_wg10(ctx, tail, s) : launch_bootstrap_pair10(ctx, tail, s);
+        }
+        return 0;
     } else {
         return launch_bootstrap_w<11, 4>(ctx, a, s);   // inverse pass-1/untwist twiddles stay in global memory: 4 gates per CU fit
     }

@@ -1,23 +1,34 @@
-// rtfhe_kernels_pair.hpp -- the bootstrap kernel with TWO WAVES PER GATE (N = 1024).
+// rtfhe_kernels_pair.hpp -- the bootstrap kernel with TWO WAVES PER GATE (N = 1024): the throughput shape.
 //
-// k_bootstrap gives a gate one wavefront.  A launch with at most one gate per SIMD (the headline batch: 1024 gates on
-// 1024 SIMDs) then leaves every SIMD with a single resident wave, and a lone wave issues one FP64 instruction per
-// ~6.75 cycles where two waves sharing the SIMD reach one per ~5.4 (profiles/ubench).  Here the two waves of a pair split
-// one gate's CMUX step; the arithmetic and its order are unchanged (see cmux_step for the reference citations):
+// k_bootstrap gives a gate one wavefront.  With one gate per SIMD (the headline batch: 1024 gates on 1024 SIMDs) every
+// SIMD then holds a single wave, and a lone wave issues one FP64 instruction per ~6.75 cycles where two waves sharing
+// the SIMD reach one per ~5.4 (profiles/ubench/fp64_lds_issue_rates.log).  LDS (20 KiB of accumulator, exchange
+// buffers and rotation amounts per gate) rules out more gates per CU, so here two waves share ONE gate's CMUX step.
+// The arithmetic and its order are unchanged (see cmux_step for the reference citations):
 //
-//   wave 0 ("b side")                               wave 1 ("a side")
-//   decompose b-poly, transforms of rows 0..2       decompose a-poly, transforms of rows 3..5        (spectra stay in VGPRs)
-//   s0 = 0 + rows 0..2 of component 0  -> LDS
-//   ------------------------------------------ barrier -----------------------------------------------
-//   s1 = 0 + rows 0..2 of component 1  -> LDS       s0 += rows 3..5 of component 0 -> LDS
-//   ------------------------------------------ barrier -----------------------------------------------
-//   inverse transform of s0, += into the b-poly     s1 += rows 3..5 of component 1; inverse, += into the a-poly
+//   side 0 (wave w, owns the b-poly)                       side 1 (wave w + GATES, owns the a-poly)
+//   gather/decompose b-poly, transforms of rows 0..2       gather/decompose a-poly, transforms of rows 3..5   (spectra in VGPRs)
+//   P: s0 = 0 + rows 0..2 of component 0    -> hand0
+//   --------------------------------------------- barrier 1 ----------------------------------------------------
+//   Q: s1 = 0 + rows 0..2 of component 1    -> hand1       Q: s0 = hand0 + rows 3..5 of component 0  -> hand0
+//   --------------------------------------------- barrier 2 ----------------------------------------------------
+//   s0 = hand0; inverse transform, += into the b-poly      R: s1 = hand1 + rows 3..5 of component 1; inverse, += into the a-poly
 //
-// The fold order of every accumulator point is rows 0, 1, ..., 5 from +0.0, exactly as in the reference
-// (trgsw.rs:290-299): the partial sums travel, the products are never re-associated.  Each wave only ever touches its
-// own accumulator polynomial, so two barriers per step suffice.  Hand-off buffers are the (idle) exchange buffers:
-// partial s0 and final s0 through wave 0's, partial s1 through wave 1's -- each is written only while its owner is
-// between transforms, in program order with the barriers.
+// * Fold order: every accumulator point sums rows 0, 1, ..., 5 from +0.0, exactly as the reference does
+//   (trgsw.rs:290-299): the partial sums travel between the waves, products are never re-associated -> bit-identical.
+// * Each side only ever reads and writes its OWN accumulator polynomial, so a side may run ahead into the next step's
+//   gather and transforms; the two barriers per step order the hand-offs only.  hand0 / hand1 are the (then idle)
+//   exchange buffers of side 0 / side 1: each is written only while its owner is between transforms, in program order
+//   with the barriers.
+// * Key rows go through a two-buffer register ring that runs ACROSS steps (each buffer is refilled right after its
+//   multiply-accumulate retires; the last refills of a step fetch rows of the next).  Slot Q is the same code for both
+//   sides, so the ring buffers are live in the same way on both paths at every control-flow merge -- the other
+//   arrangements tried (per-side straight-line schedules, prefetch that only one side holds across a barrier) made the
+//   register allocator spill 50-240 VGPRs, and scratch reloads share the vmcnt queue with the prefetches.
+// * Priority schedule (see prio_point): the SIMD arbiter is strictly priority-then-age ordered, so with fixed
+//   priorities one side races to each barrier and the SIMD then runs one wave; flipping side 0's priority twice per
+//   step makes both sides reach the barriers together (8.16 -> 7.70 ms per 1024 gates).
+// Measured (profiles/r01_pair): 7.70-7.75 ms per 1024 gates vs 8.69 ms for k_bootstrap's 4-wave shape, same outputs.
 #pragma once
 
 #include "rtfhe_kernels.hpp"
@@ -27,11 +38,7 @@ namespace rtfhe {
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
 // spaces, i.e. s_waitcnt vmcnt(0): it would wait for the key rows prefetched across it.  Hand-offs here go through LDS.
 __device__ __forceinline__ void lds_barrier() {
-#ifdef PAIR_SYNCTHREADS
-    __syncthreads();
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 template <int R>
@@ -51,8 +58,7 @@ struct PairLds {
     static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers
     static_assert(XB >= (size_t)G::P * sizeof(cplx), "an exchange buffer pair must hold one spectrum");
     __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * G::N * 4 + (size_t)npad * 4 + 2 * XB; }
-    __host__ __device__ static constexpr size_t prog_offset(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
-    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return prog_offset(gates, npad) + 64; }   // + progress words
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
 // GATES gates per workgroup, 2 * GATES waves: wave w serves gate (w % GATES) as side (w / GATES)
@@ -69,8 +75,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     const int slot = wave % GATES, side = wave / GATES;
     cplx* tw = reinterpret_cast<cplx*>(smem);
     for (int idx = tid; idx < G::TW_TOTAL; idx += NT) tw[idx] = a.tw[idx];
-    volatile int* prog = reinterpret_cast<volatile int*>(smem + PairLds::prog_offset(GATES, a.npad));   // see `pace`
-    if (tid < 2 * GATES) prog[tid] = 0;
     const cplx* twf = tw;
     const cplx* twi = tw + G::TW_DIR;
 
@@ -119,21 +123,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #else
 #define PAIR_STAMP(k) do { } while (0)
 #endif
-    // Pacing.  The SIMD's arbiter is strictly priority-then-age ordered: of two waves that both have work, one runs at
-    // full speed and the other gets the leftovers (~1/3 speed), so the favoured wave of a pair reaches every barrier
-    // early and the SIMD then runs a single wave.  Each wave publishes its progress (in units of equal work) at every
-    // half-transform and raises its priority when it is behind its partner, lowers it when ahead: both sides then
-    // reach the barriers together.
-    const int partner = side ? slot : slot + GATES;
-    auto pace = [&](int p) {
-#ifdef PAIR_PACE
-        prog[wave] = p;                      // every lane stores the same word: no divergent branch
-        const int other = __builtin_amdgcn_readfirstlane(prog[partner]);
-        // one opaque statement, no compiler-visible control flow (extra basic blocks inside the transforms cost spills)
-        asm volatile("s_cmp_lt_i32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 2f\n1:\n\ts_setprio 3\n2:"
-                     :: "s"(p), "s"(other) : "scc");
-#endif
-    };
     const size_t trgsw_cplx = (size_t)2 * L * 2 * R * 64;
     // Key rows in consumption order rc = 0..5: (row rc % 3, component rc / 3) of this side.  A ring of two 8-point buffers
     // runs across steps: each is refilled right after its multiply-accumulate retires, two MACs ahead of its use, the
@@ -150,6 +139,23 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         fetch(bA, 0, side ? 0 : 1);
         fetch(bB, 0, side ? 1 : 0);
     }
+    // Priority schedule.  The SIMD's arbiter is strictly priority-then-age ordered: of two waves that both have work one
+    // runs at (nearly) full speed and the other on the leftovers, so with fixed priorities the favoured side reaches every
+    // barrier early and the SIMD then runs a single wave.  Side 1 stays at priority 1; side 0 runs at 2 from
+    // PAIR_RAISE_AT to PAIR_LOWER_AT and at 0 for the rest of the step, which splits the time between the barriers
+    // about evenly (measured: profiles/r01_pair/priority_schedule_ab.log).  Points: 0..5 after each half transform,
+    // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
+#ifndef PAIR_LOWER_AT
+#define PAIR_LOWER_AT 2
+#endif
+#ifndef PAIR_RAISE_AT
+#define PAIR_RAISE_AT 9
+#endif
+    auto prio_point = [&](int point) {   // one opaque statement each: no compiler-visible control flow inside the transforms
+        if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
+        if (point == PAIR_RAISE_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
+    };
+    if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
                 xi[jj][m] = (double)decomp_digit(u[R + m], BGBIT, jj);
             }
             fft_forward_a<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
-            pace(20 * i + (side ? 8 : 6) + 4 * jj);
+            prio_point(2 * jj);
             fft_forward_b<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
-            pace(20 * i + (side ? 10 : 8) + 4 * jj);
+            prio_point(2 * jj + 1);
             PAIR_STAMP(1 + jj);
         }
 
@@ -203,9 +209,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
             mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, i, 4);
             put(hand0);
         }
-        pace(20 * i + 18);
+        prio_point(6);
         PAIR_STAMP(4);
         lds_barrier();
+        prio_point(7);
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
         // on top of side 0's partial sum -> hand0
@@ -214,9 +221,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         mac_row<R>(sre, sim, bB, xr[1], xi[1]); fetch(bB, side ? i : nxt, side ? 3 : 0);
         mac_row<R>(sre, sim, bA, xr[2], xi[2]); fetch(bA, side ? i : nxt, side ? 4 : 1);
         put(side ? hand0 : hand1);
-        pace(20 * i + 20);
+        prio_point(8);
         PAIR_STAMP(6);
         lds_barrier();
+        prio_point(9);
         PAIR_STAMP(7);
         // slot R (side 1): component 1 over rows 3..5 on top of side 0's partial sum; side 0 picks up the finished s0
         if (side == 1) {
@@ -224,7 +232,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
             mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 5);
             mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, nxt, 0);
             mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, nxt, 1);
-            pace(20 * i + 22);
         } else {
             get(hand0);
         }
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
             poly[c + P] += trunc_to_torus(sim[m]);
         }
         wave_lds_sync();
-        pace(20 * i + (side ? 26 : 24));
+        prio_point(10);
         PAIR_STAMP(9);
     }
     __builtin_amdgcn_s_setprio(0);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase cycle shares of the two-waves-per-gate kernel (library built with -DRTFHE_WG_STAMPS into
-scripts/ubench/librtfhe_stamps.so).  Phases per CMUX step: 0 gather/decompose | 1 2 3 transforms | 4 barrier 0 | 5 init | 6 7 8 MAC rows of component 0 |
-9 hand-off | 10 MAC rows of component 1 | 11 (side 0: put) | 12 barrier 1 | 13 (side 1 block total is 5..10) | 14 barrier 2 |
-15 tail (inverse, update)."""
+scripts/ubench/librtfhe_stamps.so).  Phases per CMUX step: 0 gather/decompose | 1 2 3 forward transforms | 4 slot P (side 0:
+component 0 of rows 0..2) | 5 barrier 1 | 6 slot Q | 7 barrier 2 | 8 slot R (side 1) / pick-up of s0 (side 0) |
+9 inverse transform + accumulator update."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
