@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 os.environ["RTFHE_FORCE_WAVES"] = "2"
 import rustfhe_amd.build as b
-b.LIB = os.path.join(ROOT, "scripts", "ubench", "librtfhe_stamps.so")
+b.LIB = os.path.join(ROOT, "scripts", "ubench", os.environ.get("RTFHE_STAMPS_LIB", "librtfhe_stamps.so"))
 b.build = lambda *a, **k: b.LIB
 import rustfhe_amd as R
 P = R.Params()

@@ -210,3 +210,27 @@ def test_all_kernel_shapes_match_golden(params, keys, gold_gate, force, monkeypa
         assert np.array_equal(acc[0], acc[1]) and np.array_equal(acc[0], acc[2])
     finally:
         e.close()
+
+
+def test_segmented_dispatch_matches_single_launch(engine, params, keys, monkeypatch):
+    """Batches that are not whole rounds of 4 gates per CU are split into a two-waves-per-gate launch plus a remainder
+    launch (latency kernel for <= 2 gates per CU, one more round otherwise): same words as one wave-per-gate launch of
+    the whole batch, for plain batches and for blind-rotate outputs (different output stride)."""
+    import rustfhe_amd as R
+    rng = np.random.default_rng(77)
+    count = 1024 + 700
+    b0, b1 = rng.integers(0, 2, count), rng.integers(0, 2, count)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    monkeypatch.setenv("RTFHE_FORCE_WAVES", "4")
+    single = R.Engine(R.Params(), 0)
+    try:
+        single.load_bk_fft(keys.bk_f)
+        single.load_ksk(keys.ksk)
+        for cnt in (1024 + 100, 1024 + 700):
+            out = engine.gate_batch(R.XOR, c0[:cnt], c1[:cnt])
+            assert keys.decrypt_bits(out) == list(b0[:cnt] ^ b1[:cnt])
+            assert np.array_equal(out, single.gate_batch(R.XOR, c0[:cnt], c1[:cnt]))
+        acc = engine.blind_rotate_batch(c0[:1024 + 8], 3)
+        assert np.array_equal(acc, single.blind_rotate_batch(c0[:1024 + 8], 3))
+    finally:
+        single.close()
