@@ -57,7 +57,7 @@ extern "C" {
     pub fn rtfhe_gate_batch_dev(ctx: *mut rtfhe_ctx, op: c_int, d_in0: *const c_void, d_in1: *const c_void, d_out: *mut c_void,
                                 count: usize, stream: *mut c_void) -> c_int;
     pub fn rtfhe_circuit_wave_dev(ctx: *mut rtfhe_ctx, d_ops: *const c_void, d_idx0: *const c_void, d_idx1: *const c_void,
-                                  d_idx_out: *const c_void, d_wires: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
+                                  d_idx_out: *const c_void, d_wires: *mut c_void, num_wires: usize, count: usize, stream: *mut c_void) -> c_int;
     pub fn rtfhe_sync(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
     pub fn rtfhe_timer_begin(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
     pub fn rtfhe_timer_end(ctx: *mut rtfhe_ctx, stream: *mut c_void, ms: *mut f64, launches: *mut i64) -> c_int;

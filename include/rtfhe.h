@@ -116,9 +116,12 @@ int rtfhe_gate_batch_dev(rtfhe_ctx *ctx, int op, const void *d_in0, const void *
                          size_t count, void *stream);
 /* one dependency wave of a gate netlist (the build-side counterpart of nander's eager tree walk, nander/src/lib.rs:72-89):
  * gate g reads rows idx0[g] and idx1[g] of the wire table d_wires (u32[num_wires][n+1]), applies ops[g] and writes row
- * idx_out[g]; all four arrays are int32[count] in device memory.  Gates of one call must be independent. */
+ * idx_out[g]; all four arrays are int32[count] in device memory.  Gates of one call must be independent.  Indices and
+ * opcodes are validated on the device against num_wires: an offending gate is skipped (nothing is read or written through
+ * it) and the next rtfhe_sync returns RTFHE_ERR_INVALID. */
 int rtfhe_circuit_wave_dev(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0, const void *d_idx1,
-                           const void *d_idx_out, void *d_wires, size_t count, void *stream);
+                           const void *d_idx_out, void *d_wires, size_t num_wires, size_t count, void *stream);
+/* waits for `stream`; also reports (once) a netlist gate skipped since the previous call */
 int rtfhe_sync(rtfhe_ctx *ctx, void *stream);
 /* device-side timing of the launches enqueued by the *_dev calls between begin and end (HIP events on
  * `stream`); end returns total milliseconds and the number of kernel launches */

@@ -246,7 +246,7 @@ class CircuitRunner:
         import torch
         st = torch.cuda.current_stream().cuda_stream
         for ops, i0, i1, io, cnt in self.waves:
-            self.e.circuit_wave_dev(ops, i0, i1, io, self.wires, cnt, st)
+            self.e.circuit_wave_dev(ops, i0, i1, io, self.wires, self.R * self.net.num_wires, cnt, st)
         return self
 
     def outputs(self):

@@ -174,6 +174,7 @@ struct rtfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
+    int32_t* d_fault = nullptr;            // set by a kernel that skipped a netlist gate (bad wire index / opcode)
     unsigned long long* d_dbg = nullptr;   // RTFHE_WG_STAMPS builds: 128 words of phase timings
     int num_cus = 256;
     int force_waves = 0;   // RTFHE_FORCE_WAVES=1|4|8 (tuning knob: 1 = workgroup-per-gate kernel)
@@ -357,7 +358,7 @@ int launch_bootstrap_ntt_w(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
 
 int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
                      size_t count, hipStream_t s, const int32_t* d_ops = nullptr, const int32_t* d_idx0 = nullptr,
-                     const int32_t* d_idx1 = nullptr, const int32_t* d_idx_out = nullptr) {
+                     const int32_t* d_idx1 = nullptr, const int32_t* d_idx_out = nullptr, int32_t num_wires = 0) {
     if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
     if (mode == MODE_GATE && !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "key-switching key not loaded");
     if (count == 0) return 0;
@@ -368,6 +369,7 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.count = (int)count; a.op = op; a.n = ctx->p.n; a.steps = steps; a.mode = mode; a.ksw = ctx->ksw;
     a.npad = (ctx->p.n + 1 + 63) / 64 * 64;
     a.ops = d_ops; a.idx0 = d_idx0; a.idx1 = d_idx1; a.idx_out = d_idx_out;
+    a.num_wires = num_wires; a.fault = ctx->d_fault;
     a.dbg = ctx->d_dbg;
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
         if (int rc = ntt_prepare(ctx)) return rc;
@@ -435,6 +437,16 @@ int upload_twiddles(rtfhe_ctx* ctx) {
     return 0;
 }
 
+// TRGSWRepF::from (trgsw.rs:68-76): ifft_torus = forward transform of the key words viewed as signed i32, from the
+// device copy of the torus-form key into the device spectra
+int transform_bk_from_torus(rtfhe_ctx* ctx) {
+    const size_t words = bk_word_count(ctx->p);
+    FftArgs a{ctx->d_tw, ctx->d_bk_torus, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l};
+    if (int rc = launch_fft(ctx, true, a, ctx->stream)) return rc;
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int use(rtfhe_ctx* ctx) {
     if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
     HIPCHECK(ctx, hipSetDevice(ctx->device));
@@ -485,6 +497,8 @@ int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
         if (const char* e = std::getenv("RTFHE_WG_MAX_GATES")) ctx->wg_max = std::atoi(e);
     }
     if (!rc) rc = upload_twiddles(ctx);
+    if (!rc && (hipMalloc((void**)&ctx->d_fault, 4) != hipSuccess || hipMemset(ctx->d_fault, 0, 4) != hipSuccess))
+        rc = fail(ctx, RTFHE_ERR_HIP, "hipMalloc failed");
     if (!rc && hipStreamCreate(&ctx->stream) != hipSuccess) rc = fail(ctx, RTFHE_ERR_HIP, "hipStreamCreate failed");
     if (!rc && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess))
         rc = fail(ctx, RTFHE_ERR_HIP, "hipEventCreate failed");
@@ -508,6 +522,7 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+    if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->d_bk) (void)hipFree(ctx->d_bk);
     if (ctx->d_bk_torus) (void)hipFree(ctx->d_bk_torus);
     if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
@@ -543,7 +558,11 @@ int rtfhe_set_twiddles(rtfhe_ctx* ctx, const double* ifft_table, const double* f
     if (!ifft_table || !fft_table) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     ctx->tw.import_ref(ifft_table, fft_table);
     HIPCHECK(ctx, hipDeviceSynchronize());
-    return upload_twiddles(ctx);
+    if (int rc = upload_twiddles(ctx)) return rc;
+    // a key loaded in torus form was transformed with the old tables: redo it (spectra loaded through rtfhe_load_bk_fft
+    // are the caller's and stay as they are)
+    if (ctx->has_bk && ctx->d_bk_torus) return transform_bk_from_torus(ctx);
+    return 0;
 }
 
 int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
@@ -551,15 +570,10 @@ int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
     if (!bk) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     const size_t words = bk_word_count(ctx->p);
     if (!ctx->d_bk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx)));
-    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, words * 4)) return rc;
-    HIPCHECK(ctx, hipMemcpy(ctx->d_a, bk, words * 4, hipMemcpyHostToDevice));
     if (!ctx->d_bk_torus) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_bk_torus, words * 4));
-    HIPCHECK(ctx, hipMemcpy(ctx->d_bk_torus, ctx->d_a, words * 4, hipMemcpyDeviceToDevice));
+    HIPCHECK(ctx, hipMemcpy(ctx->d_bk_torus, bk, words * 4, hipMemcpyHostToDevice));
     ctx->ntt_ready = false;
-    // TRGSWRepF::from (trgsw.rs:68-76): ifft_torus = forward transform of the words viewed as signed i32
-    FftArgs a{ctx->d_tw, ctx->d_a, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l};
-    if (int rc = launch_fft(ctx, true, a, ctx->stream)) return rc;
-    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = transform_bk_from_torus(ctx)) return rc;
     ctx->has_bk = true;
     return 0;
 }
@@ -618,16 +632,25 @@ int rtfhe_gate_batch_dev(rtfhe_ctx* ctx, int op, const void* d_in0, const void* 
 }
 
 int rtfhe_circuit_wave_dev(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, const void* d_idx1, const void* d_idx_out,
-                           void* d_wires, size_t count, void* stream) {
+                           void* d_wires, size_t num_wires, size_t count, void* stream) {
     if (int rc = use(ctx)) return rc;
     if (!d_ops || !d_idx0 || !d_idx1 || !d_idx_out || !d_wires) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (num_wires == 0 || num_wires > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "num_wires out of range");
     return launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, count, (hipStream_t)stream,
-                            (const int32_t*)d_ops, (const int32_t*)d_idx0, (const int32_t*)d_idx1, (const int32_t*)d_idx_out);
+                            (const int32_t*)d_ops, (const int32_t*)d_idx0, (const int32_t*)d_idx1, (const int32_t*)d_idx_out,
+                            (int32_t)num_wires);
 }
 
 int rtfhe_sync(rtfhe_ctx* ctx, void* stream) {
     if (int rc = use(ctx)) return rc;
     HIPCHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    // netlist waves validate their indices on the device; a skipped gate is reported here, once
+    int32_t fault = 0;
+    HIPCHECK(ctx, hipMemcpy(&fault, ctx->d_fault, 4, hipMemcpyDeviceToHost));
+    if (fault) {
+        HIPCHECK(ctx, hipMemset(ctx->d_fault, 0, 4));
+        return fail(ctx, RTFHE_ERR_INVALID, "netlist wave: wire index or opcode out of range (those gates were skipped)");
+    }
     return 0;
 }
 
@@ -704,6 +727,7 @@ int rtfhe_external_product_batch(rtfhe_ctx* ctx, const int32_t* bk_index, const 
     if (!bk_index || !trlwe || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
     if (count == 0) return 0;
+    if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
     for (size_t g = 0; g < count; g++)
         if (bk_index[g] < 0 || bk_index[g] >= ctx->p.n) return fail(ctx, RTFHE_ERR_INVALID, "bk_index out of range");
     const size_t bytes = count * 2 * (size_t)ctx->p.N * 4;
@@ -736,6 +760,7 @@ int rtfhe_key_switch_batch(rtfhe_ctx* ctx, const uint32_t* tlwe1, uint32_t* out,
     if (!tlwe1 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (!ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "key-switching key not loaded");
     if (count == 0) return 0;
+    if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
     const size_t in_bytes = count * ((size_t)ctx->p.N + 1) * 4, out_bytes = count * ((size_t)ctx->p.n + 1) * 4;
     if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;
     if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, out_bytes)) return rc;
@@ -752,6 +777,7 @@ static int run_fft_batch(rtfhe_ctx* ctx, bool forward, const void* src, void* re
     if (int rc = use(ctx)) return rc;
     if (!src || !res) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (count == 0) return 0;
+    if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
     const size_t N = (size_t)ctx->p.N;
     const size_t in_bytes = count * N * (forward ? 4 : 8), out_bytes = count * N * (forward ? 8 : 4);
     if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;

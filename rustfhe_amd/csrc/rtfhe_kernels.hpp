@@ -37,6 +37,8 @@ struct BootstrapArgs {
     const int32_t* idx0;
     const int32_t* idx1;
     const int32_t* idx_out;
+    int32_t num_wires;       // netlist mode: rows in the wire table; indices and opcodes are checked against it on the device
+    int32_t* fault;          // netlist mode: set to 1 when a gate was skipped for an out-of-range index / unknown opcode
     unsigned long long* dbg;   // diagnostic builds only (RTFHE_WG_STAMPS): per-phase cycle sums of workgroup 0
 };
 
@@ -53,6 +55,26 @@ __device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1
         case OP_ANDNY: return (x1 - x0) - (isb ? c8 : 0u);   // hom_and(-x0, x1), the second AND of hom_mux (tfhe.rs:34)
         default:      return x0;
     }
+}
+
+// Where gate g reads and writes.  Netlist gates with a wire index outside [0, num_wires) or an unknown opcode are
+// skipped (ok = false: they run on row 0 and store nothing) and reported through *fault -- never dereferenced.
+struct GateIo { const uint32_t* p0; const uint32_t* p1; uint32_t* out; int op; bool ok; };
+__device__ __forceinline__ GateIo gate_io(const BootstrapArgs& a, int g) {
+    const size_t w = (size_t)a.n + 1;
+    GateIo io;
+    if (a.idx0) {
+        int i0 = a.idx0[g], i1 = a.idx1[g], o = a.idx_out[g];
+        io.op = a.ops[g];
+        const unsigned nw = (unsigned)a.num_wires;
+        io.ok = (unsigned)i0 < nw && (unsigned)i1 < nw && (unsigned)o < nw && (unsigned)io.op <= (unsigned)OP_ANDNY;
+        if (!io.ok) { i0 = 0; i1 = 0; o = 0; io.op = OP_COPY; if (a.fault) *a.fault = 1; }
+        io.p0 = a.in0 + (size_t)i0 * w; io.p1 = a.in0 + (size_t)i1 * w; io.out = a.out + (size_t)o * w;
+    } else {
+        io.p0 = a.in0 + (size_t)g * w; io.p1 = a.in1 + (size_t)g * w; io.out = a.out + (size_t)g * w;
+        io.op = a.op; io.ok = true;
+    }
+    return io;
 }
 
 // One external product / CMUX on the wave-private accumulator in LDS.
@@ -240,13 +262,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
 
     const int n = a.n;
     // pre-step + mod switch (tfhe.rs:97, 107-108): b floor, a_i rounded, both to [0, 2N)
+    const GateIo io = gate_io(a, g);
+    if (!io.ok) return;
     {
-        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
-        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
-        const int op = a.ops ? a.ops[g] : a.op;
         constexpr int SH = 32 - LOGN - 1;
         for (int i = lane; i <= n; i += 64) {
-            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
             abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
         }
     }
@@ -289,8 +310,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap(const BootstrapArgs
         accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[mm] : (0u - av[mm]);
     }
     wave_lds_sync();
-    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n,
-                                            a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1), lane);
+    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n, io.out, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

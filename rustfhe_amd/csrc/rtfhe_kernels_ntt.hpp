@@ -102,13 +102,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap_ntt(const NttBootst
     const double* twf = tw;
     const double* twi = tw + ntt::TW_DIR_PAD;
     const int n = a.n;
+    const GateIo io = gate_io(a, g);
+    if (!io.ok) return;
     {
-        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
-        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
-        const int op = a.ops ? a.ops[g] : a.op;
         constexpr int SH = 32 - LOGN - 1;
         for (int i = lane; i <= n; i += 64) {
-            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
             abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
         }
     }
@@ -146,8 +145,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap_ntt(const NttBootst
         accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[m] : (0u - av[m]);
     }
     wave_lds_sync();
-    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n,
-                                            a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1), lane);
+    key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n, io.out, lane);
 }
 
 struct NttBkArgs {

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 
     // idle pairs of the last workgroup shadow the last gate (they take part in every barrier) and store nothing
     const int g_raw = blockIdx.x * GATES + slot;
-    const bool live = g_raw < a.count;
-    const int g = live ? g_raw : a.count - 1;
+    const int g = g_raw < a.count ? g_raw : a.count - 1;
+    const GateIo io = gate_io(a, g);
+    const bool live = g_raw < a.count && io.ok;      // a skipped netlist gate still takes part in every barrier
 
     unsigned char* gbase = smem + PairLds::TW + (size_t)slot * PairLds::gate_bytes(a.npad);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);
@@ -95,12 +96,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 
     const int n = a.n;
     {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108)
-        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
-        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
-        const int op = a.ops ? a.ops[g] : a.op;
         constexpr int SH = 32 - LOGN - 1;
         for (int i = lane + 64 * side; i <= n; i += 128) {
-            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
             abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
         }
     }
@@ -287,7 +285,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     __syncthreads();
     if (side == 0 && live) {
         const uint32_t bprime = accbuf[0];
-        uint32_t* out = a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1);
+        uint32_t* out = io.out;
 #pragma unroll
         for (int q = 0; q < KSQ; q++) {
             const uint4 o = part[q * 64];

@@ -57,13 +57,12 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     const int n = a.n;
 
     for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * NW) tw[idx] = a.tw[idx];
+    const GateIo io = gate_io(a, g);
+    if (!io.ok) return;                             // the whole workgroup serves this gate: uniform exit
     {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108)
-        const uint32_t* p0 = a.in0 + (size_t)(a.idx0 ? a.idx0[g] : g) * (n + 1);
-        const uint32_t* p1 = a.idx0 ? a.in0 + (size_t)a.idx1[g] * (n + 1) : a.in1 + (size_t)g * (n + 1);
-        const int op = a.ops ? a.ops[g] : a.op;
         constexpr int SH = 32 - LOGN - 1;
         for (int i = tid; i <= n; i += 64 * NW) {
-            const uint32_t t = gate_linear(op, p0[i], p1[i], i == n);
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
             abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
         }
     }
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
 #pragma unroll
     for (int q = 0; q < KSQ; q++) part[(wave * KSQ + q) * 64 + lane] = sum[q];
     __syncthreads();
-    uint32_t* out = a.out + (size_t)(a.idx_out ? a.idx_out[g] : g) * (n + 1);
+    uint32_t* out = io.out;
     const uint32_t* pw = reinterpret_cast<const uint32_t*>(spec);
     for (int col = tid; col <= n; col += 64 * NW) {
         // column col lives in uint4 slot (col/4) = lane + 64 q, element col % 4

@@ -127,9 +127,11 @@ class Engine:
         self._ck(self.L.rtfhe_gate_batch_dev(self.h, op, self._dev(d_in0), self._dev(d_in1), self._dev(d_out),
                                              count, C.c_void_p(stream) if stream else None))
 
-    def circuit_wave_dev(self, d_ops, d_idx0, d_idx1, d_idx_out, d_wires, count, stream=None):
+    def circuit_wave_dev(self, d_ops, d_idx0, d_idx1, d_idx_out, d_wires, num_wires, count, stream=None):
+        """One dependency wave of a netlist; wire indices / opcodes are validated on the device against num_wires
+        (rows of d_wires) and a violation surfaces as RtfheError at the next sync()."""
         self._ck(self.L.rtfhe_circuit_wave_dev(self.h, self._dev(d_ops), self._dev(d_idx0), self._dev(d_idx1),
-                                               self._dev(d_idx_out), self._dev(d_wires), count,
+                                               self._dev(d_idx_out), self._dev(d_wires), num_wires, count,
                                                C.c_void_p(stream) if stream else None))
 
     def sync(self, stream=None):

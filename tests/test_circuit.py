@@ -104,3 +104,31 @@ def test_mux_via_netlist_matches_mux_batch(engine, keys, gold_gate):
     run = CircuitRunner(engine, net, 1)
     run.set_inputs(np.stack([gold_gate["in0"][2], gold_gate["in0"][0], gold_gate["in1"][1]])[None])
     assert np.array_equal(run.run().outputs()[0, 0], gold_gate["mux_out"])
+
+
+@pytest.mark.gpu
+def test_netlist_wave_rejects_bad_wire_indices(engine, keys):
+    """Wire indices / opcodes of a netlist wave are checked on the device: the offending gate is skipped, the other gates
+    of the wave run, the next sync reports RTFHE_ERR_INVALID once, and the context stays usable."""
+    import torch
+    import rustfhe_amd as R
+    n1 = engine.p.n + 1
+    ct = keys.encrypt_bits([1, 0, 1])
+    W = 8
+    wires = torch.zeros((W, n1), dtype=torch.int32, device="cuda")
+    wires[:3] = torch.from_numpy(ct.view(np.int32)).cuda()
+    dev = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    #            ok: w3 = NAND(w0, w1)   bad input index      bad output index   bad opcode
+    ops, i0, i1, io = dev([R.NAND, R.NAND, R.NAND, 99]), dev([0, 12345678, 0, 0]), dev([1, 1, 1, 1]), dev([3, 4, -1, 5])
+    engine.circuit_wave_dev(ops, i0, i1, io, wires, W, 4, st)
+    with pytest.raises(R.RtfheError) as ei:
+        engine.sync(st)
+    assert ei.value.code == R._ffi.ERR_INVALID
+    out = wires.cpu().numpy().view(np.uint32)
+    assert keys.decrypt_bits(out[3:4]) == [1]                       # NAND(1, 0)
+    assert not out[4].any() and not out[5].any()                    # skipped gates wrote nothing
+    engine.sync(st)                                                 # reported once
+    engine.circuit_wave_dev(dev([R.AND]), dev([0]), dev([2]), dev([6]), wires, W, 1, st)
+    engine.sync(st)
+    assert keys.decrypt_bits(wires[6:7].cpu().numpy().view(np.uint32)) == [1]

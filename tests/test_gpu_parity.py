@@ -234,3 +234,24 @@ def test_segmented_dispatch_matches_single_launch(engine, params, keys, monkeypa
         assert np.array_equal(acc, single.blind_rotate_batch(c0[:1024 + 8], 3))
     finally:
         single.close()
+
+
+def test_twiddle_import_retransforms_a_torus_form_key(params, keys, gold_gate):
+    """rtfhe_set_twiddles after rtfhe_load_bk_torus: the key's spectra are recomputed with the imported tables (importing
+    a perturbed table and then the original one must give the golden words again)."""
+    import rustfhe_amd as R
+    e = R.Engine(R.Params(), 0)
+    try:
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        ifft, fft = e.twiddles()
+        g = [k for k in range(len(gold_gate["ops"])) if gold_gate["ops"][k] == R.NAND][:4]
+        in0, in1, want = gold_gate["in0"][g], gold_gate["in1"][g], gold_gate["out"][g]
+        assert np.array_equal(e.gate_batch(R.NAND, in0, in1), want)
+        bad = ifft.copy()
+        bad[8] = np.nextafter(bad[8], 2.0)                 # one forward-twist cosine off by one ulp
+        e.set_twiddles(bad, fft)
+        e.set_twiddles(ifft, fft)
+        assert np.array_equal(e.gate_batch(R.NAND, in0, in1), want)
+    finally:
+        e.close()
