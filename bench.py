@@ -156,7 +156,7 @@ def main():
             "outputs_decrypt_correctly": ok and bad == 0.0,
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-                         "kernel": "k_bootstrap_pair" if args.backend == "fft64-mirror" else "k_bootstrap_ntt", "avg_launch_ms": round(1e3 * launch_s, 3),
+                         "kernel": "k_bootstrap_pair" if args.backend == "fft64-mirror" else "k_bootstrap_ntt_pair", "avg_launch_ms": round(1e3 * launch_s, 3),
                          "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G, "launches_per_batch": round(launches / args.steps, 2)},
         }
         if args.backend == "fft64-mirror" and G % 1024 == 0:

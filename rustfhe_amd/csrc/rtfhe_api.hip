@@ -356,6 +356,18 @@ int launch_bootstrap_ntt_w(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     return 0;
 }
 
+int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    constexpr int GATES = 4;
+    auto k = k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, GATES>;
+    const size_t lds = NttPairLds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    NttBootstrapArgs a{b, ctx->d_ntt_tw, ctx->d_ntt_bk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(128 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
 int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
                      size_t count, hipStream_t s, const int32_t* d_ops = nullptr, const int32_t* d_idx0 = nullptr,
                      const int32_t* d_idx1 = nullptr, const int32_t* d_idx_out = nullptr, int32_t num_wires = 0) {
@@ -373,7 +385,10 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.dbg = ctx->d_dbg;
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
         if (int rc = ntt_prepare(ctx)) return rc;
-        return launch_bootstrap_ntt_w<4>(ctx, a, s);   // 6-wave workgroups measured slower (64 k vs 76 k gates/s): LDS-bound
+        // two waves per gate: 11.5 ms per 1024 gates vs 13.3 ms one wave per gate in 4-wave workgroups (RTFHE_FORCE_WAVES=4);
+        // 6-wave workgroups of the latter measured slower still (64 k vs 76 k gates/s): LDS-bound
+        if (ctx->force_waves == 4) return launch_bootstrap_ntt_w<4>(ctx, a, s);
+        return launch_bootstrap_ntt_pair(ctx, a, s);
     }
     return ctx->logn == 10 ? launch_bootstrap_t<10>(ctx, a, s) : launch_bootstrap_t<11>(ctx, a, s);
 }

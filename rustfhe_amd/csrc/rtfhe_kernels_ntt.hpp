@@ -4,6 +4,7 @@
 #pragma once
 
 #include "rtfhe_kernels.hpp"
+#include "rtfhe_kernels_pair.hpp"
 #include "rtfhe_ntt.hpp"
 
 namespace rtfhe {
@@ -146,6 +147,187 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bootstrap_ntt(const NttBootst
     }
     wave_lds_sync();
     key_switch_wave<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, bprime, a.ksk, a.ksw, n, io.out, lane);
+}
+
+// Two waves per gate on the NTT backend (see rtfhe_kernels_pair.hpp for why: one gate per SIMD leaves the FP64 pipe with a
+// single wave).  Exact integer arithmetic carries no fold-order constraint, so the split is symmetric: side s gathers and
+// decomposes accumulator polynomial s, transforms its three digit polynomials and accumulates BOTH components over its
+// three key rows; then the sides swap the component the other one owns (through their own idle exchange buffers), add,
+// run one inverse transform each and update their own polynomial.  Sums are sums of the same exact integers as in
+// k_bootstrap_ntt => identical words.
+struct NttPairLds {
+    static constexpr size_t TW = (size_t)ntt::TW_TOTAL * sizeof(double);
+    static constexpr size_t XB = (size_t)ntt::XSLOTS * sizeof(double);
+    static_assert(ntt::XSLOTS >= ntt::N, "an exchange buffer must hold one spectrum");
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * ntt::N * 4 + (size_t)npad * 4 + 2 * XB; }
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
+};
+
+#ifndef NTT_PAIR_LOWER_AT
+#define NTT_PAIR_LOWER_AT 2
+#endif
+#ifndef NTT_PAIR_RAISE_AT
+#define NTT_PAIR_RAISE_AT 8
+#endif
+
+template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
+__global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const NttBootstrapArgs args) {
+    constexpr int N = ntt::N, R = ntt::R, LOGN = 10, NT = 128 * GATES;
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    const BootstrapArgs& a = args.b;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave % GATES, side = wave / GATES;
+    for (int idx = tid; idx < ntt::TW_TOTAL; idx += NT) tw[idx] = args.ntt_tw[idx];
+    const double* twf = tw;
+    const double* twi = tw + ntt::TW_DIR_PAD;
+
+    const int g_raw = blockIdx.x * GATES + slot;
+    const int g = g_raw < a.count ? g_raw : a.count - 1;
+    const GateIo io = gate_io(a, g);
+    const bool live = g_raw < a.count && io.ok;      // idle / skipped pairs still take part in every barrier
+
+    unsigned char* gbase = smem + NttPairLds::TW + (size_t)slot * NttPairLds::gate_bytes(a.npad);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);
+    uint32_t* abar = accbuf + 2 * N;
+    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + (size_t)a.npad * 4);
+    double* xb1 = xb0 + ntt::XSLOTS;
+    double* myx = side ? xb1 : xb0;
+    double* peerx = side ? xb0 : xb1;
+    uint32_t* poly = accbuf + side * N;
+    const int n = a.n;
+    {
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane + 64 * side; i <= n; i += 128) {
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
+            abar[i] = (i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH);
+        }
+    }
+    __syncthreads();
+    {
+        const int bbar = (int)abar[n];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            const int e = (c + bbar) & (2 * N - 1);
+            poly[c] = side ? 0u : ((e >> LOGN) ? 0xE0000000u : 0x20000000u);
+        }
+    }
+    wave_lds_sync();
+    // priority schedule as in k_bootstrap_pair: side 1 at 1, side 0 at 2 from NTT_PAIR_RAISE_AT to NTT_PAIR_LOWER_AT, else 0
+    auto prio_point = [&](int point) {   // `point` may be a run-time (scalar) value: selection by scalar ALU, the branch stays inside the asm
+        const int lower = __builtin_amdgcn_readfirstlane((point == NTT_PAIR_LOWER_AT) & (side == 0));
+        const int raise = __builtin_amdgcn_readfirstlane((point == NTT_PAIR_RAISE_AT) & (side == 0));
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(lower) : "scc");
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(raise) : "scc");
+    };
+    if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+
+    const size_t trgsw_doubles = (size_t)2 * L * 2 * N;
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        const double* bk_i = args.ntt_bk + (size_t)i * trgsw_doubles;
+        uint32_t u[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            u[m] = ((rotated_coef<10>(poly, c, r) - poly[c]) + M) ^ M;
+        }
+        double s0[R], s1[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { s0[m] = 0.0; s1[m] = 0.0; }
+#pragma unroll 1
+        for (int jj = 0; jj < L; jj++) {
+            double x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) x[m] = (double)decomp_digit(u[m], BGBIT, jj);
+            const double2* b0p = ntt_bk_row(bk_i, side * L + jj, 0, lane);
+            const double2* b1p = ntt_bk_row(bk_i, side * L + jj, 1, lane);
+            double2 b0[R / 2], b1[R / 2];
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
+            ntt::forward_a(x, twf, myx, lane);
+            prio_point(2 * jj);
+            ntt::forward_b(x, twf, myx, lane);
+            prio_point(2 * jj + 1);
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) {
+                s0[2 * q] += ntt::modmul(x[2 * q], b0[q].x);     s0[2 * q + 1] += ntt::modmul(x[2 * q + 1], b0[q].y);
+                s1[2 * q] += ntt::modmul(x[2 * q], b1[q].x);     s1[2 * q + 1] += ntt::modmul(x[2 * q + 1], b1[q].y);
+            }
+        }
+        // swap: export the component the other side owns through the own (now idle) exchange buffer
+        {
+            double2* ex = reinterpret_cast<double2*>(myx) + lane;
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) ex[q * 64] = side ? make_double2(s0[2 * q], s0[2 * q + 1]) : make_double2(s1[2 * q], s1[2 * q + 1]);
+        }
+        prio_point(6);
+        lds_barrier();
+        prio_point(7);
+        double x[R];
+        {
+            const double2* im = reinterpret_cast<const double2*>(peerx) + lane;
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) {
+                const double2 v = im[q * 64];
+                x[2 * q] = (side ? s1[2 * q] : s0[2 * q]) + v.x;
+                x[2 * q + 1] = (side ? s1[2 * q + 1] : s0[2 * q + 1]) + v.y;
+            }
+        }
+        lds_barrier();                    // both imports done: the exchange buffers are free for the inverse transforms
+        prio_point(8);
+        ntt::inverse(x, twi, myx, lane);
+#pragma unroll
+        for (int m = 0; m < R; m++) poly[lane + 64 * m] += ntt::to_torus(x[m]);
+        wave_lds_sync();
+        prio_point(9);
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        if (live) {
+            uint32_t* o = a.out + (size_t)g * 2 * N + side * N;
+            for (int c = lane; c < N; c += 64) o[c] = poly[c];
+        }
+        return;
+    }
+    // sample extract (side 1 owns the a-poly) + key switch split over both sides, as in k_bootstrap_pair
+    if (side == 1) {
+        uint32_t av[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) av[m] = poly[lane + 64 * m];
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            poly[(N - c) & (N - 1)] = (c == 0) ? av[m] : (0u - av[m]);
+        }
+    }
+    __syncthreads();
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, side * (N / 2), (side + 1) * (N / 2), a.ksk, a.ksw, sum, lane);
+    uint4* part = reinterpret_cast<uint4*>(xb1) + lane;
+    if (side == 1) {
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) part[q * 64] = sum[q];
+    }
+    __syncthreads();
+    if (side == 0 && live) {
+        const uint32_t bprime = accbuf[0];
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) {
+            const uint4 o = part[q * 64];
+            const int col = 4 * (lane + 64 * q);
+            const uint32_t sv[4] = {sum[q].x + o.x, sum[q].y + o.y, sum[q].z + o.z, sum[q].w + o.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (col + e <= n) io.out[col + e] = ((col + e == n) ? bprime : 0u) - sv[e];
+        }
+    }
 }
 
 struct NttBkArgs {

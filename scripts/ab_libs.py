@@ -27,6 +27,8 @@ for path in libs:
     h = C.c_void_p(); assert L.rtfhe_ctx_create(C.byref(P), 0, C.byref(h)) == 0
     e.h = h
     e.load_bk_torus(bk); e.load_ksk(ksk)
+    if os.environ.get("RTFHE_BACKEND") == "ntt":
+        e.set_backend(1)
     engines.append(e); outs.append(torch.empty_like(d0))
 times = [[] for _ in libs]
 for r in range(rounds + 1):

@@ -23,6 +23,8 @@ for f in shapes:
     os.environ["RTFHE_FORCE_WAVES"] = f
     e = R.Engine(P, 0)
     e.load_bk_torus(bk); e.load_ksk(ksk)
+    if os.environ.get("RTFHE_BACKEND") == "ntt":
+        e.set_backend(1)
     engines.append(e); outs.append(torch.empty_like(d0))
 times = [[] for _ in shapes]
 for r in range(rounds + 1):

@@ -96,3 +96,23 @@ def test_ntt_needs_torus_key(keys):
         assert ei.value.code == R._ffi.ERR_STATE
     finally:
         e.close()
+
+
+def test_ntt_two_waves_per_gate_kernel_gives_the_same_words(ntt_engine, params, keys, gold_gate, monkeypatch):
+    """The NTT backend's default kernel is k_bootstrap_ntt_pair (two waves per gate, symmetric split); RTFHE_FORCE_WAVES=4
+    selects the one-wave-per-gate kernel: sums of the same exact integers => the same words, for gates, ragged counts and
+    blind-rotate prefixes."""
+    import rustfhe_amd as R
+    monkeypatch.setenv("RTFHE_FORCE_WAVES", "4")
+    e = R.Engine(R.Params(), 0)
+    try:
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        e.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        in0, in1 = gold_gate["in0"][:7], gold_gate["in1"][:7]
+        for cnt in (7, 1, 4):
+            assert np.array_equal(e.gate_batch(R.NAND, in0[:cnt], in1[:cnt]), ntt_engine.gate_batch(R.NAND, in0[:cnt], in1[:cnt]))
+        assert np.array_equal(e.gate_batch(R.XOR, in0[:3], in1[:3]), ntt_engine.gate_batch(R.XOR, in0[:3], in1[:3]))
+        assert np.array_equal(e.blind_rotate_batch(in0[:5], 9), ntt_engine.blind_rotate_batch(in0[:5], 9))
+    finally:
+        e.close()
