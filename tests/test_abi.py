@@ -21,6 +21,42 @@ def test_header_symbols_all_exported():
     assert declared == set(R._ffi.EXPORTED_SYMBOLS), declared ^ set(R._ffi.EXPORTED_SYMBOLS)
 
 
+def test_header_is_plain_c99_and_a_c_host_links(tmp_path):
+    """include/rtfhe.h is the drop-in boundary: plain C (no C++ or torch types), usable from a C host; without a GPU the
+    library must refuse to create a context (no CPU fallback) -- checked here from C, linked against the built .so."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    src = tmp_path / "host.c"
+    src.write_text('''#include <stdio.h>
+#include "rtfhe.h"
+int main(void) {
+    rtfhe_params p; rtfhe_ctx *ctx = 0;
+    rtfhe_default_params(&p);
+    if (p.n != 635 || p.N != 1024 || p.l != 3 || p.bgbit != 6 || p.ks_t != 8 || p.ks_basebit != 2) return 2;
+    int rc = rtfhe_ctx_create(&p, 0, &ctx);
+    printf("%d %d %s\\n", rc, rtfhe_device_count(), rtfhe_version());
+    if (rc == 0) rtfhe_ctx_destroy(ctx);
+    return 0;
+}
+''')
+    import rustfhe_amd as R
+    R.load()
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    lib = R._ffi.lib_path()
+    exe = tmp_path / "host"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib,
+                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, ndev = int(out.stdout.split()[0]), int(out.stdout.split()[1])
+    assert (rc == 0) == (ndev > 0)                  # a context exists exactly when a HIP device does
+    if ndev == 0:
+        assert rc == R._ffi.ERR_NO_DEVICE
+
+
 def test_library_is_a_gfx950_code_object():
     import rustfhe_amd as R
     R.load()
