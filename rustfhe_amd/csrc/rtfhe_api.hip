@@ -630,11 +630,18 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
     if (int rc = use(ctx)) return rc;
     if (!ksk) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     const size_t rows = ksk_rows(ctx->p), w = (size_t)ctx->p.n + 1, ksw = (size_t)ctx->ksw;
-    // device layout: rows padded to a multiple of 4 words (16-byte loads) + one all-zero row that digit 0 selects
+    // staging: rows padded to a multiple of 4 words (16-byte loads) + one all-zero row
     std::vector<uint32_t> padded((rows + 1) * ksw, 0u);
     for (size_t r = 0; r < rows; r++) std::memcpy(padded.data() + r * ksw, ksk + r * w, w * 4);
-    if (!ctx->d_ksk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ksk, padded.size() * 4));
-    HIPCHECK(ctx, hipMemcpy(ctx->d_ksk, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, padded.size() * 4)) return rc;
+    HIPCHECK(ctx, hipMemcpy(ctx->d_a, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+    // device layout: the rows of two adjacent levels pre-summed (see ks_accumulate) + one all-zero row that "both digits 0" selects
+    const size_t dev_rows = (size_t)ks_dev_rows(ctx->p.N, ctx->p.ks_t, ctx->p.ks_basebit);
+    if (!ctx->d_ksk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ksk, (dev_rows + 1) * ksw * 4));
+    KskCombineArgs a{(const uint32_t*)ctx->d_a, ctx->d_ksk, ctx->p.N, ctx->ksw};
+    hipLaunchKernelGGL((k_ksk_combine<8, 2>), dim3(4096), dim3(256), 0, ctx->stream, a);
+    HIPCHECK(ctx, hipGetLastError());
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_ksk = true;
     return 0;
 }

@@ -20,7 +20,7 @@ enum { MODE_GATE = 0, MODE_BLIND_ROTATE = 1 };
 struct BootstrapArgs {
     const cplx* tw;          // [Geo::TW_TOTAL] forward table then inverse table
     const cplx* bk;          // device layout [n][2l][2][R][64]
-    const uint32_t* ksk;     // device layout [N*t*(base-1) + 1][ksw]; last row all zero
+    const uint32_t* ksk;     // device layout [N*(t/2)*(base^2-1) + 1][ksw] (pairs of levels pre-summed, see ks_accumulate); last row all zero
     const uint32_t* in0;     // [count][n+1]
     const uint32_t* in1;     // [count][n+1] (may alias in0)
     uint32_t* out;           // MODE_GATE: [count][n+1];  MODE_BLIND_ROTATE: [count][2][N]
@@ -165,29 +165,39 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
 // ks_accumulate sums the selected rows for coefficients [i_begin, i_end) into per-lane uint4 accumulators (lane holds
 // columns 4 (lane + 64 q) .. +3).  Rows are added in a different order than the reference's (i, l) loop: wrapping u32
 // addition is commutative and associative, so the result is bit-identical.
+//
+// For the same reason the device copy of the key holds, per coefficient, the rows of KS_GROUP = 2 adjacent levels already
+// summed: row (i, p, c) = KS[i][2p][d0] + KS[i][2p+1][d1] with c = d0 * base + d1 in 1 .. base^2 - 1 (k_ksk_combine).  A gate
+// then gathers t/2 rows per coefficient of which 15/16 are non-zero instead of t rows of which 3/4 are: 9.8 MB instead of
+// 15.6 MB per gate through the L2 (the key switch is L2-bandwidth bound: all gates of a launch reach it together), for a
+// 2.5x larger table (156 MB, still resident in the Infinity Cache next to the bootstrapping key).
+constexpr int KS_GROUP = 2;
+__host__ __device__ constexpr int ks_dev_rows(int N, int t, int basebit) { return N * (t / KS_GROUP) * ((1 << (basebit * KS_GROUP)) - 1); }
+
 template <int LOGN, int KS_T, int KS_BB, int KSQ>
 __device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprime, int i_begin, int i_end,
                                               const uint32_t* __restrict__ ksk, int ksw, uint4 (&sum)[KSQ], int lane) {
     constexpr int N = 1 << LOGN;
-    constexpr int BASE1 = (1 << KS_BB) - 1;
+    static_assert(KS_T % KS_GROUP == 0, "levels are grouped in pairs");
+    constexpr int PT = KS_T / KS_GROUP, PBB = KS_BB * KS_GROUP, PBASE1 = (1 << PBB) - 1;
     constexpr uint32_t ROUND = (32 - KS_T * KS_BB) != 0 ? (1u << (32 - KS_T * KS_BB - 1)) : 0u;
-    const int zero_row = N * KS_T * BASE1;
+    const int zero_row = ks_dev_rows(N, KS_T, KS_BB);
     // lanes past the end of a row re-read its last 16 bytes (branch-free); the columns they accumulate are never stored
     int idx[KSQ];
 #pragma unroll
     for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); idx[q] = min(lane + 64 * q, ksw / 4 - 1); }
-    // KS_UI coefficients per iteration: KS_UI * KS_T rows (3 x 16 B per lane each) in flight per wave
-    constexpr int KS_UI = 2;
+    // KS_UI coefficients per iteration: KS_UI * PT rows (3 x 16 B per lane each) in flight per wave
+    constexpr int KS_UI = 4;
 #pragma unroll 1
     for (int i = i_begin; i < i_end; i += KS_UI) {
-        uint4 v[KS_UI][KS_T][KSQ];
+        uint4 v[KS_UI][PT][KSQ];
 #pragma unroll
         for (int k = 0; k < KS_UI; k++) {
             const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(aprime[i + k] + ROUND));
 #pragma unroll
-            for (int l = 0; l < KS_T; l++) {
-                const uint32_t d = (u >> (32 - KS_BB * (l + 1))) & ((1u << KS_BB) - 1u);
-                const int row = d ? (((i + k) * KS_T + l) * BASE1 + (int)d - 1) : zero_row;   // digit 0 -> the shared all-zero row
+            for (int l = 0; l < PT; l++) {
+                const uint32_t c = (u >> (32 - PBB * (l + 1))) & ((1u << PBB) - 1u);          // digits 2l, 2l+1 side by side
+                const int row = c ? (((i + k) * PT + l) * PBASE1 + (int)c - 1) : zero_row;   // both digits 0 -> the shared all-zero row
                 const uint4* p = reinterpret_cast<const uint4*>(ksk + (size_t)row * ksw);
 #pragma unroll
                 for (int q = 0; q < KSQ; q++) v[k][l][q] = p[idx[q]];
@@ -196,11 +206,36 @@ __device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprim
 #pragma unroll
         for (int k = 0; k < KS_UI; k++)
 #pragma unroll
-            for (int l = 0; l < KS_T; l++)
+            for (int l = 0; l < PT; l++)
 #pragma unroll
                 for (int q = 0; q < KSQ; q++) {
                     sum[q].x += v[k][l][q].x; sum[q].y += v[k][l][q].y; sum[q].z += v[k][l][q].z; sum[q].w += v[k][l][q].w;
                 }
+    }
+}
+
+// device key-switching key from the reference's [N][t][base-1] rows (padded to ksw words, + the all-zero row at `zero_src`):
+// one block per output row (i, p, c)
+struct KskCombineArgs {
+    const uint32_t* raw;     // [N*t*(base-1) + 1][ksw]
+    uint32_t* out;           // [ks_dev_rows + 1][ksw]; the last row is all zero
+    int32_t N, ksw;
+};
+template <int KS_T, int KS_BB>
+__global__ __launch_bounds__(256) void k_ksk_combine(const KskCombineArgs a) {
+    constexpr int BASE1 = (1 << KS_BB) - 1, PT = KS_T / KS_GROUP, PBB = KS_BB * KS_GROUP, PBASE1 = (1 << PBB) - 1;
+    static_assert(KS_GROUP == 2, "pairs of levels");
+    const int rows = a.N * PT * PBASE1, zero_src = a.N * KS_T * BASE1;
+    for (int r = blockIdx.x; r <= rows; r += gridDim.x) {
+        uint32_t* dst = a.out + (size_t)r * a.ksw;
+        if (r == rows) { for (int w = threadIdx.x; w < a.ksw; w += blockDim.x) dst[w] = 0u; continue; }
+        const int c = r % PBASE1 + 1, ip = r / PBASE1, p = ip % PT, i = ip / PT;
+        const int d0 = c >> KS_BB, d1 = c & BASE1;
+        const int s0 = d0 ? ((i * KS_T + 2 * p) * BASE1 + d0 - 1) : zero_src;
+        const int s1 = d1 ? ((i * KS_T + 2 * p + 1) * BASE1 + d1 - 1) : zero_src;
+        const uint32_t* r0 = a.raw + (size_t)s0 * a.ksw;
+        const uint32_t* r1 = a.raw + (size_t)s1 * a.ksw;
+        for (int w = threadIdx.x; w < a.ksw; w += blockDim.x) dst[w] = r0[w] + r1[w];
     }
 }
 
