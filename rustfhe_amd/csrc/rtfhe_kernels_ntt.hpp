@@ -226,6 +226,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
 
     const size_t trgsw_doubles = (size_t)2 * L * 2 * N;
+    uint32_t own[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) own[m] = poly[lane + 64 * m];
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
-            u[m] = ((rotated_coef<10>(poly, c, r) - poly[c]) + M) ^ M;
+            u[m] = ((rotated_coef<10>(poly, c, r) - own[m]) + M) ^ M;
         }
         double s0[R], s1[R];
 #pragma unroll
@@ -282,7 +285,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
         prio_point(8);
         ntt::inverse(x, twi, myx, lane);
 #pragma unroll
-        for (int m = 0; m < R; m++) poly[lane + 64 * m] += ntt::to_torus(x[m]);
+        for (int m = 0; m < R; m++) {       // the new coefficients also stay in registers for the gather that follows
+            own[m] = poly[lane + 64 * m] + ntt::to_torus(x[m]);
+            poly[lane + 64 * m] = own[m];
+        }
         wave_lds_sync();
         prio_point(9);
     }

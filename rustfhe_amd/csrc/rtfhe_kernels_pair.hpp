@@ -113,6 +113,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
     }
     wave_lds_sync();
+    // this side's own coefficients (lane + 64 mm) are handed from the update at the end of a step to the gather that
+    // opens the next one in registers: the gather then reads only the rotated coefficients from LDS
+    uint32_t own[2 * R];
+#pragma unroll
+    for (int mm = 0; mm < 2 * R; mm++) own[mm] = poly[lane + 64 * mm];
 
 #ifdef RTFHE_WG_STAMPS
     unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
@@ -166,8 +171,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
         for (int mm = 0; mm < 2 * R; mm++) {
             const int c = ln + 64 * mm;
-            const uint32_t own = poly[c];
-            u[mm] = ((rotated_coef<LOGN>(poly, c, r) - own) + M) ^ M;
+            u[mm] = ((rotated_coef<LOGN>(poly, c, r) - own[mm]) + M) ^ M;
         }
         PAIR_STAMP(0);
         double xr[L][R], xi[L][R];
@@ -240,8 +244,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
-            poly[c] += trunc_to_torus(sre[m]);
-            poly[c + P] += trunc_to_torus(sim[m]);
+            own[m] = poly[c] + trunc_to_torus(sre[m]);          // kept for the gather that follows immediately
+            own[R + m] = poly[c + P] + trunc_to_torus(sim[m]);
+            poly[c] = own[m];
+            poly[c + P] = own[R + m];
         }
         wave_lds_sync();
         prio_point(10);
