@@ -31,7 +31,8 @@ struct WgLds {
     static constexpr size_t SBUF = SPEC + (size_t)2 * L * G::P * sizeof(cplx);       // cplx[2][P]
     static constexpr size_t XBUF = SBUF + (size_t)2 * G::P * sizeof(cplx);           // double[2l][XSLOTS]
     static constexpr size_t ABAR = XBUF + (size_t)2 * L * G::XSLOTS * sizeof(double);
-    __host__ __device__ static constexpr size_t bytes(int npad) { return ABAR + (size_t)npad * 4; }
+    __host__ __device__ static constexpr size_t flags(int npad) { return ABAR + (size_t)npad * 4; }   // int[2]: hand-off of rows 2l-2, 2l-1
+    __host__ __device__ static constexpr size_t bytes(int npad) { return flags(npad) + 16; }
 };
 
 template <int LOGN, int L, int BGBIT, int KS_T, int KS_BB, int KSQ>
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     typedef WgLds<LOGN, L> S;
     constexpr int N = G::N, P = G::P, R = G::R, NW = S::NW, ROWS = 2 * L;
     static_assert(R == NW, "the MAC phase gives each of the 8 waves one of the R = 8 points a lane holds");
-    static_assert(ROWS <= NW, "one forward transform per wave");
+    static_assert(ROWS + 2 == NW, "rows 0..2l-1 start on waves 0..2l-1; the last two rows finish on waves 2l, 2l+1");
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     extern __shared__ __align__(16) unsigned char smem[];
     cplx* tw = reinterpret_cast<cplx*>(smem + S::TW);
@@ -50,7 +51,11 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     uint32_t* abar = reinterpret_cast<uint32_t*>(smem + S::ABAR);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double* xbuf = reinterpret_cast<double*>(smem + S::XBUF) + (size_t)(wave < ROWS ? wave : 0) * G::XSLOTS;
+    // row this wave works on in the F phase: waves 2l, 2l+1 take over rows 2l-2, 2l-1 half way (see the F phase)
+    const int frow = wave < ROWS ? wave : wave - 2;
+    double* xbuf = reinterpret_cast<double*>(smem + S::XBUF) + (size_t)frow * G::XSLOTS;
+    volatile int* flags = reinterpret_cast<volatile int*>(smem + S::flags(a.npad));
+    if (tid < 2) flags[tid] = 0;
     const cplx* twf = tw;
     const cplx* twi = tw + G::TW_DIR;
     const int g = blockIdx.x;                       // grid = count
@@ -101,10 +106,14 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
         WG_STAMP(0);
-        // ---- F: one digit polynomial per wave (trgsw.rs:269-289) ----
+        // ---- F: one digit polynomial per row (trgsw.rs:269-289).  Six transforms on four SIMDs: rows 0..3 run whole on
+        // waves 0..3 (one per SIMD); rows 4, 5 START on waves 4, 5 (which share SIMDs 0, 1 with waves 0, 1): gather, twist,
+        // pass 1 and the write half of the first exchange, at raised priority -- and FINISH on waves 6, 7 (SIMDs 2, 3):
+        // read half, pass 2, second exchange, pass 3, spectrum store.  The hand-off is a release/acquire flag in LDS.
         if (wave < ROWS) {
             const int h = wave / L, jj = wave - h * L;
             const uint32_t* poly = accbuf + h * N;
+            if (wave >= ROWS - 2) __builtin_amdgcn_s_setprio(3);
             double re[R], im[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
@@ -114,9 +123,27 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                 re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
                 im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
             }
-            // second exchange buffer = this wave's own (still unwritten) spectrum slot
-            fft_forward<LOGN, true>(re, im, twf, xbuf, lane, reinterpret_cast<double*>(spec + (size_t)wave * P));
-            cplx* dst = spec + (size_t)wave * P + lane;
+            // second exchange buffer = this row's own (still unwritten) spectrum slot
+            double* xim = reinterpret_cast<double*>(spec + (size_t)wave * P);
+            if (wave < ROWS - 2) {
+                fft_forward<LOGN, true>(re, im, twf, xbuf, lane, xim);
+                cplx* dst = spec + (size_t)wave * P + lane;
+#pragma unroll
+                for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
+            } else {
+                fft_forward_head<LOGN>(re, im, twf, xbuf, xim, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                flags[wave - (ROWS - 2)] = i + 1;
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else {
+            const int k = wave - ROWS;
+            while (__builtin_amdgcn_readfirstlane(flags[k]) != i + 1) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double re[R], im[R];
+            double* xim = reinterpret_cast<double*>(spec + (size_t)frow * P);
+            fft_forward_tail<LOGN>(re, im, twf, xbuf, xim, lane);
+            cplx* dst = spec + (size_t)frow * P + lane;
 #pragma unroll
             for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
         }
