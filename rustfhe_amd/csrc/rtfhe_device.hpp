@@ -330,8 +330,8 @@ __device__ __forceinline__ void fft_forward_head(double (&re)[Geo<LOGN>::R], dou
     exchange_write_dual<LOGN, 1, 2>(re, im, xbuf, xim, lane);
 }
 template <int LOGN>
-__device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
-                                                 double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
+__device__ __forceinline__ void fft_forward_mid(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
+                                                double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
     Tw<R - 1> w2;
@@ -339,6 +339,11 @@ __device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], dou
     exchange_read_dual<LOGN, 1, 2>(re, im, xbuf, xim, lane);
     wave_lds_sync();
     P12<R, G::LR - 1>::fwd(re, im, w2.w);
+}
+template <int LOGN>
+__device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
+                                                 double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
+    fft_forward_mid<LOGN>(re, im, tw, xbuf, xim, lane);
     fft_forward_b<LOGN, true>(re, im, tw, xbuf, lane, xim);
 }
 
