@@ -5,7 +5,9 @@
 // and single hom_nand() calls are small; here the 8 waves of a 512-thread workgroup share one gate:
 //
 //   per CMUX step (same arithmetic, same operation order as the reference -- see cmux_step for citations):
-//     F  waves 0..2l-1 : wave j gathers/decomposes digit polynomial j and runs its forward transform, spectrum -> LDS
+//     F  waves 0..2l-1 : wave j gathers/decomposes digit polynomial j and runs its forward transform, spectrum -> LDS;
+//                        the transforms of the last two rows are cut at their first exchange and finished by waves 2l, 2l+1
+//                        on the two SIMDs that host only one F-wave (release/acquire flag in LDS, no barrier)
 //     -- barrier --
 //     M  all 8 waves   : wave w owns points (lane << 3) | w of both accumulator spectra and runs their MAC chains
 //                        over the 2l rows IN ROW ORDER (the reference's fold order), BK values prefetched at step start
