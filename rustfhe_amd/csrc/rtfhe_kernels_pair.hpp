@@ -25,9 +25,10 @@
 //   sides, so the ring buffers are live in the same way on both paths at every control-flow merge -- the other
 //   arrangements tried (per-side straight-line schedules, prefetch that only one side holds across a barrier) made the
 //   register allocator spill 50-240 VGPRs, and scratch reloads share the vmcnt queue with the prefetches.
-// * Priority schedule (see prio_point): the SIMD arbiter is strictly priority-then-age ordered, so with fixed
-//   priorities one side races to each barrier and the SIMD then runs one wave; flipping side 0's priority twice per
-//   step makes both sides reach the barriers together (8.16 -> 7.70 ms per 1024 gates).
+// * Priority schedule (see prio_point): a SIMD does not share itself evenly between two busy waves (one runs at ~0.9 of
+//   its solo speed, the other on the leftovers; s_setprio selects which), so with fixed priorities one side races to each
+//   barrier and the SIMD then runs one wave; flipping side 0's priority twice per step makes both sides reach the
+//   barriers together (8.16 -> 7.70 ms per 1024 gates).
 // Measured (profiles/r01_pair): 7.70-7.75 ms per 1024 gates vs 8.69 ms for k_bootstrap's 4-wave shape, same outputs.
 #pragma once
 
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         fetch(bA, 0, side ? 0 : 1);
         fetch(bB, 0, side ? 1 : 0);
     }
-    // Priority schedule.  The SIMD's arbiter is strictly priority-then-age ordered: of two waves that both have work one
-    // runs at (nearly) full speed and the other on the leftovers, so with fixed priorities the favoured side reaches every
-    // barrier early and the SIMD then runs a single wave.  Side 1 stays at priority 1; side 0 runs at 2 from
+    // Priority schedule.  Of two waves that both have work a SIMD runs one at (nearly) full speed and the other on the
+    // leftovers (s_setprio selects which), so with fixed priorities the favoured side reaches every barrier early and the
+    // SIMD then runs a single wave.  Side 1 stays at priority 1; side 0 runs at 2 from
     // PAIR_RAISE_AT to PAIR_LOWER_AT and at 0 for the rest of the step, which splits the time between the barriers
     // about evenly (measured: profiles/r01_pair/priority_schedule_ab.log).  Points: 0..5 after each half transform,
     // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
