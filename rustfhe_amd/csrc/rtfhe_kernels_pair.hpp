@@ -34,6 +34,14 @@
 
 #include "rtfhe_kernels.hpp"
 
+// side 0's priority schedule (see prio_point in k_bootstrap_pair); overridable for A/B builds
+#ifndef PAIR_LOWER_AT
+#define PAIR_LOWER_AT 2
+#endif
+#ifndef PAIR_RAISE_AT
+#define PAIR_RAISE_AT 9
+#endif
+
 namespace rtfhe {
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
@@ -149,12 +157,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     // PAIR_RAISE_AT to PAIR_LOWER_AT and at 0 for the rest of the step, which splits the time between the barriers
     // about evenly (measured: profiles/r01_pair/priority_schedule_ab.log).  Points: 0..5 after each half transform,
     // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
-#ifndef PAIR_LOWER_AT
-#define PAIR_LOWER_AT 2
-#endif
-#ifndef PAIR_RAISE_AT
-#define PAIR_RAISE_AT 9
-#endif
     auto prio_point = [&](int point) {   // one opaque statement each: no compiler-visible control flow inside the transforms
         if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
         if (point == PAIR_RAISE_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
