@@ -1,39 +1,158 @@
 #!/usr/bin/env python3
 """bench.py -- HomNAND gates/sec on N MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (pre-step, blind rotate, sample extract, identity key switch)
-over one batch of `--gates` independent NAND gates per GPU, ONE kernel launch, inputs and keys already
-resident in HBM.  Weak scaling: every rank owns its own batch, no data-path collective (gates are
-independent).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path (pre-step, blind rotate, sample extract, identity key switch) over one batch of
+independent NAND gates, inputs and keys already resident in HBM.  One process per GPU; rank 0 prints ONE JSON line.
 
-    python bench.py                                   # 1 GPU, defaults finish in well under a minute
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py                          # 1 GPU, BASELINE configs[1]: 1024 gates, one kernel launch per step
+    python bench.py --gpus 8                 # spawns 8 ranks itself (RCCL), 1024 gates per GPU per step, weak scaling
+    python bench.py --gpus 8 --workload config3   # BASELINE configs[2]: 8192 gates per GPU, the whole batch starts on
+                                                  # rank 0's GPU: scatter over xGMI -> bootstrap -> gather, all timed
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W      # the same ranks under an external launcher
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: before torch is imported or any
+HIP call is made it starts N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON line
+and exits non-zero if any child did.  RTFHE_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs
+(ranks share the cards; collectives run on the CPU).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# SURVEY 8(d) / BASELINE.md 4: algorithmic bytes one gate must consume at N=1024, n=635, l=3
+# ---- SURVEY 8(d) / BASELINE.md 4: algorithmic bytes one gate must consume at N=1024, n=635, l=3 (the streaming model) ----
 BK_BYTES_PER_GATE = 635 * 2 * 6 * 1024 * 8            # 62,423,040  whole bootstrapping key once
 KSK_BYTES_PER_GATE = 1024 * 8 * 3 // 4 * 2544          # 15,630,336  expected touched key-switch rows
 IO_BYTES_PER_GATE = 3 * 2544                           #      7,632  two inputs + one output
 ALG_BYTES_PER_GATE = BK_BYTES_PER_GATE + KSK_BYTES_PER_GATE + IO_BYTES_PER_GATE   # 78,061,008
 HBM_PEAK = 8.0e12                                      # MI355X_MICROARCH.md: 8 TB/s spec
 
+# ---- the ceiling that binds: FP64 vector issue without FMA (MI355X_MICROARCH.md chip table) ----
+CUS, SIMDS_PER_CU, DP_LANES_PER_CLK, CLOCK_HZ = 256, 4, 16, 2.4e9
+FP64_VALU_PEAK = CUS * SIMDS_PER_CU * DP_LANES_PER_CLK * CLOCK_HZ     # 39.32e12 lane-ops/s: one v_add/v_mul_f64 lane result each
 
+
+def dp_wave_instr_per_cmux(N=1024, l=3):
+    """FP64-rate VALU wave-instructions one CMUX step costs, derived from the transform structure of
+    rustfhe_amd/csrc/rtfhe_device.hpp (checked against the built kernel's ISA by tests/test_dp_opcount.py):
+    the mirror arithmetic may not fuse, so every product and every sum is one v_mul_f64 / v_add_f64."""
+    P = N // 2
+    R = P // 64                               # points per lane
+    LR = R.bit_length() - 1
+    low = (P.bit_length() - 1) - 2 * LR       # radix-2 stages left for pass 3
+    twist = 6 * R                             # 4 products + 2 sums per point
+    pass12 = 2 * LR * (R // 2) * 10           # two passes of LR twiddled stages: 4 sums + 4 products + 2 sums per butterfly
+    pass3_tw = max(low - 2, 0) * (R // 2) * 10
+    size4_size2 = 2 * R + 2 * R               # halfnn = 2 and 1: sums only
+    transform = twist + pass12 + pass3_tw + size4_size2           # 360 at N = 1024, forward and inverse alike
+    mac = 8 * R                               # hadamard 4 products + 2 sums, fold 2 sums, per point
+    trunc_add = 2 * R                         # the magic-constant add of trunc_to_torus, per inverse transform
+    arith = 2 * l * transform + 2 * transform + 2 * 2 * l * mac + 2 * trunc_add
+    cvt = 2 * l * 2 * R + 2 * 2 * R           # v_cvt_f64_i32 per digit, v_trunc_f64 per output word
+    return {"add_mul": arith, "cvt_trunc": cvt, "total": arith + cvt, "transform": transform, "mac_row": mac}
+
+
+def kernel_src_hash():
+    """Identifies the device code a PMC profile was taken with (profiles/pmc_traffic.json is refused when it differs)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rustfhe_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher (parent process: never imports torch, never touches HIP)
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(nranks, child_cmd, timeout=None, env_extra=None):
+    """Starts `nranks` fresh processes of child_cmd with the torch.distributed environment set, relays rank 0's stdout
+    to ours, and returns (exit code, rank-0 stdout lines).  Exit code is non-zero if ANY rank failed; on the first
+    failure the other ranks are terminated (each is its own process, killed by exact PID)."""
+    port = _free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(list(child_cmd), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    import threading
+    lines, rc, t0 = [], 0, time.time()
+
+    def relay():                               # rank 0 prints the one JSON line; everything it prints is relayed
+        for line in procs[0].stdout:
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    try:
+        pending = list(range(nranks))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.remove(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()
+            if timeout and time.time() - t0 > timeout and pending:
+                rc = rc or 124
+                for q in pending:
+                    procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        reader.join(timeout=10)
+    return rc, lines
+
+
+def launch(args):
+    rc, lines = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    if rc == 0:
+        ok = False
+        for ln in lines:
+            try:
+                ok = ok or json.loads(ln).get("n_gpus") == args.gpus
+            except ValueError:
+                pass
+        if not ok:
+            sys.stderr.write("bench.py: no JSON line with n_gpus == %d came back from rank 0\n" % args.gpus)
+            rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle / the reference's own FFT on the host cores.  Checker, never product.
+# ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(R, params, key_bk_t, ksk, in0, in1, gpu_out, per_thread):
-    """The CPU restatement (oracle/, FP64 mirror of the reference's spqlios) timed on this host's cores.
-    Checker/baseline only -- never on the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
+    import numpy as np
     import orc
     threads = max(1, len(os.sched_getaffinity(0)))
     sample = min(len(in0), threads * per_thread)
@@ -42,13 +161,15 @@ def cpu_baseline(R, params, key_bk_t, ksk, in0, in1, gpu_out, per_thread):
     bk_f = np.empty(key_bk_t.size, np.float64)
     orc.lib().orc_trgsw_to_fft(pl.h, key_bk_t.ctypes.data_as(C.POINTER(C.c_uint32)),
                                bk_f.ctypes.data_as(C.POINTER(C.c_double)), key_bk_t.size // p.N)
+    timing = "timed from the moment every thread holds its FFT plan to the last thread's last gate (thread and plan creation outside)"
     out, secs = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:sample], in1[:sample], threads)
     one, secs1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:4], in1[:4], 1)
     port = {
         "value": round(sample / secs, 2), "unit": "gates/s", "cores": threads, "kind": "port",
-        "sample": "%d NAND gates (%d per thread, one independent gate stream per thread), oracle/tfhe_oracle.c "
-                  "FP64 mirror of the reference spqlios FFT, gcc -O3 -march=native -ffp-contract=off" % (sample, per_thread),
-        "single_thread_ms_per_gate": round(1e3 * secs1 / 4, 2),
+        "sample": "%d NAND gates of the same batch (%d per thread, one independent gate stream per thread; %d hardware threads = "
+                  "os.sched_getaffinity, SMT siblings included), oracle/tfhe_oracle.c FP64 mirror of the reference spqlios FFT, "
+                  "gcc -O3 -march=native -ffp-contract=off; %s" % (sample, per_thread, threads, timing),
+        "seconds": round(secs, 2), "single_thread_ms_per_gate": round(1e3 * secs1 / 4, 2),
         "matches_gpu_bit_exact": bool(np.array_equal(out, gpu_out[:sample])),
     }
     if not orc.have_ref():
@@ -60,28 +181,23 @@ def cpu_baseline(R, params, key_bk_t, ksk, in0, in1, gpu_out, per_thread):
     one_r, secs_r1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:4], in1[:4], 1, backend=orc.BACKEND_HOOK)
     return {
         "value": round(sample / secs_r, 2), "unit": "gates/s", "cores": threads, "kind": "reference",
-        "sample": "%d NAND gates (%d per thread, one gate stream + one Spqlios handle per thread): the reference's own compiled "
-                  "spqlios AVX FFT (oracle/_ref, flags of utils/build.rs) under the C restatement of its Rust glue" % (sample, per_thread),
-        "single_thread_ms_per_gate": round(1e3 * secs_r1 / 4, 2),
+        "sample": "%d NAND gates of the same batch (%d per thread, one gate stream + one Spqlios handle per thread; %d hardware threads "
+                  "= os.sched_getaffinity, SMT siblings included): the reference's own compiled spqlios AVX FFT (oracle/_ref, flags of "
+                  "utils/build.rs) under the C restatement of its Rust glue; %s" % (sample, per_thread, threads, timing),
+        "seconds": round(secs_r, 2), "single_thread_ms_per_gate": round(1e3 * secs_r1 / 4, 2),
         "matches_gpu_bit_exact": bool(np.array_equal(out_r, gpu_out[:sample])),
         "port": port,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--gates", type=int, default=1024, help="gates per GPU per step (BASELINE configs[1]: 1024)")
-    ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact"], default="fft64-mirror",
-                    help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-gates-per-thread", type=int, default=8)
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
+    import numpy as np
     import torch
     import rustfhe_amd as R
+    from rustfhe_amd.shard import ShardedGates, engine_compute
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,32 +206,46 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # RTFHE_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("RTFHE_BENCH_BACKEND", "nccl")
-    dev = local if backend == "nccl" else local % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPUs (RCCL needs one GPU per rank)" % (world, ndev))
+    dev = local if backend == "nccl" else local % ndev
     torch.cuda.set_device(dev)
+    gpu = torch.device("cuda", dev)
+    comm = gpu if backend == "nccl" else torch.device("cpu")      # where collectives run
     dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=gpu)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+    n_gpus = dist.get_world_size() if dist is not None else 1     # the ranks the communicator really has
 
+    # ---- keys: generated ONCE (rank 0) and broadcast to the other ranks (RCCL), then loaded into each rank's engine ----
     params = R.Params()
-    key0, key1, bk, ksk = R.keygen(params, 20211003)           # same key set on every rank (replicated keys)
+    t_key = time.perf_counter()
+    if rank == 0:
+        key0, key1, bk, ksk = R.keygen(params, 20211003)
+    else:
+        key0, bk, ksk = np.empty(params.n, np.int32), np.empty(params.bk_words, np.uint32), np.empty(params.ksk_words, np.uint32)
+    if dist is not None:
+        for arr in (key0, bk, ksk):
+            t = torch.from_numpy(arr.view(np.int32)).to(comm)
+            dist.broadcast(t, src=0)
+            if rank != 0:
+                arr.view(np.int32)[:] = t.cpu().numpy()
+            del t
     eng = R.Engine(params, dev)
     eng.load_bk_torus(bk)
     eng.load_ksk(ksk)
+    key_s = time.perf_counter() - t_key
     if args.backend == "ntt-exact":
         eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
 
-    G = args.gates
-    rng = np.random.default_rng(1000 + rank)
-    b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
-    in0 = R.encrypt_bits(params, key0, b0, 5000 + 2 * rank)
-    in1 = R.encrypt_bits(params, key0, b1, 5001 + 2 * rank)
-    d_in0 = torch.from_numpy(in0.view(np.int32)).cuda()
-    d_in1 = torch.from_numpy(in1.view(np.int32)).cuda()
-    d_out = torch.empty_like(d_in0)
+    config3 = args.workload == "config3"
+    G = args.gates if args.gates else (8192 if config3 else 1024)      # gates per GPU per step
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -123,65 +253,146 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_begin(stream)
-    for _ in range(args.steps):
-        eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
-    kern_ms, launches = eng.timer_end(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    phase = None
+    if config3:
+        # the WHOLE batch (G gates per GPU) starts as ciphertexts in rank 0's HBM and the results end there
+        total = G * world
+        sg = ShardedGates(engine_compute(eng, gpu), params.n + 1, comm)
+        full0 = full1 = None
+        if rank == 0:
+            rng = np.random.default_rng(1000)
+            b0, b1 = rng.integers(0, 2, total).astype(np.uint8), rng.integers(0, 2, total).astype(np.uint8)
+            in0 = R.encrypt_bits(params, key0, b0, 5000)
+            in1 = R.encrypt_bits(params, key0, b1, 5001)
+            full0 = torch.from_numpy(in0.view(np.int32)).to(comm)
+            full1 = torch.from_numpy(in1.view(np.int32)).to(comm)
+        for _ in range(args.warmup):
+            sg.run(R.NAND, full0, full1, total)
+        barrier()
+        t0 = time.perf_counter()
+        eng.timer_begin(stream)
+        acc = {"scatter_s": 0.0, "compute_s": 0.0, "gather_s": 0.0}
+        for _ in range(args.steps):
+            res = sg.run(R.NAND, full0, full1, total, sync=torch.cuda.synchronize)
+            for k in acc:
+                acc[k] += sg.last_timing[k]
+        kern_ms, launches = eng.timer_end(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        phase = {k.replace("_s", "_ms_per_step"): round(1e3 * v / args.steps, 3) for k, v in acc.items()}
+        ok = True
+        if rank == 0:
+            out = res.cpu().numpy().view(np.uint32)
+            ok = bool(np.array_equal(R.decrypt_bits(params, key0, out), 1 - (b0 & b1)))
+    else:
+        rng = np.random.default_rng(1000 + rank)
+        b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
+        in0 = R.encrypt_bits(params, key0, b0, 5000 + 2 * rank)
+        in1 = R.encrypt_bits(params, key0, b1, 5001 + 2 * rank)
+        d_in0 = torch.from_numpy(in0.view(np.int32)).to(gpu)
+        d_in1 = torch.from_numpy(in1.view(np.int32)).to(gpu)
+        d_out = torch.empty_like(d_in0)
+        for _ in range(args.warmup):
+            eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
+        barrier()
+        t0 = time.perf_counter()
+        eng.timer_begin(stream)
+        for _ in range(args.steps):
+            eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
+        kern_ms, launches = eng.timer_end(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        out = d_out.cpu().numpy().view(np.uint32)
+        ok = bool(np.array_equal(R.decrypt_bits(params, key0, out), 1 - (b0 & b1)))
 
-    out = d_out.cpu().numpy().view(np.uint32)
-    ok = bool(np.array_equal(R.decrypt_bits(params, key0, out), 1 - (b0 & b1)))
-    t = torch.tensor([elapsed, 0.0 if ok else 1.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    t = torch.tensor([elapsed, 0.0 if ok else 1.0, kern_ms], dtype=torch.float64, device=comm)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, bad = float(t[0]), float(t[1])
+    elapsed, bad, kern_ms_max = float(t[0]), float(t[1]), float(t[2])
 
     if rank == 0:
-        value = world * G * args.steps / elapsed
-        launch_s = kern_ms * 1e-3 / args.steps          # one batch; whole rounds of 4 gates per CU are ONE kernel launch
-        achieved = ALG_BYTES_PER_GATE * G / launch_s
+        value = n_gpus * G * args.steps / elapsed
+        launch_s = kern_ms * 1e-3 / args.steps          # device time of one batch on this rank (HIP events on the launch stream)
+        mirror = args.backend == "fft64-mirror"
+        kernel = "k_bootstrap_pair" if mirror else "k_bootstrap_ntt_pair"
+        ops = dp_wave_instr_per_cmux(params.N, params.l)
         line = {
             "metric": "HomNAND gates/sec (whole node), N=1024", "value": round(value, 1), "unit": "gates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch of %d independent HomNAND gates per GPU per step, N=1024, n=635, l=3, Bgbit=6, "
-                                   "ks t=8 basebit=2 (BASELINE configs[1])" % G,
-                       "gates_per_gpu": G, "backend": args.backend, "sharding": "independent gate batches, replicated keys"},
+            "config": {"workload": ("batch of %d HomNAND gates (%d per GPU) held on rank 0's GPU: scatter over xGMI -> bootstrap -> gather, "
+                                    "all inside the timed step (BASELINE configs[2])" % (G * n_gpus, G)) if config3 else
+                                   ("batch of %d independent HomNAND gates per GPU per step (BASELINE configs[1])" % G),
+                       "params": "N=1024, n=635, l=3, Bgbit=6, ks t=8 basebit=2", "gates_per_gpu": G, "backend": args.backend,
+                       "sharding": "contiguous gate ranges, replicated keys (generated on rank 0, broadcast); " +
+                                   ("P2P scatter/gather of ciphertexts only" if config3 else "no data-path collective"),
+                       "comm_backend": (backend if dist is not None else None), "key_setup_s": round(key_s, 2)},
             "outputs_decrypt_correctly": ok and bad == 0.0,
-            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-                         "kernel": "k_bootstrap_pair" if args.backend == "fft64-mirror" else "k_bootstrap_ntt_pair", "avg_launch_ms": round(1e3 * launch_s, 3),
-                         "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G, "launches_per_batch": round(launches / args.steps, 2)},
         }
-        if args.backend == "fft64-mirror" and G % 1024 == 0:
-            # what actually binds the kernel: FP64 issue.  The mirror arithmetic may not fuse multiply-add, a
-            # gate costs 3,808 FP64 wave-instructions per CMUX, and the two waves a SIMD holds (LDS and VGPR budget) issue
-            # one every 5.4 cycles together (scripts/ubench/fp64_issue.hip, profiles/ubench/fp64_lds_issue_rates.log);
-            # clock from GRBM_GUI_ACTIVE (2.36 GHz).  One gate per SIMD per round of 1024 gates.
-            dp_ops, cyc, clk = 3808 * params.n, 5.4, 2.36e9
-            floor_s = dp_ops * cyc / clk * (G // 1024)
-            line["fp64_issue_roofline"] = {"bound": "fp64 issue, two waves per SIMD, no FMA", "dp_wave_instr_per_gate": dp_ops,
-                                           "cycles_per_instr": cyc, "clock_hz": clk, "floor_ms_per_launch": round(1e3 * floor_s, 3),
-                                           "frac": round(floor_s / launch_s, 4)}
+        if phase:
+            line["phase_ms_per_step_rank0"] = phase
+        if mirror:
+            # The ceiling that binds: FP64 vector issue with no FMA.  achieved = FP64-rate VALU lane-results per
+            # second of the dominant kernel = counted wave-instructions per gate (structure of the transform, checked against
+            # the ISA of the built kernel) x 64 lanes x gates per launch / measured launch time.
+            dp_gate = ops["total"] * params.n
+            achieved = dp_gate * 64 * G / launch_s
+            line["roofline"] = {
+                "bound": "fp64-valu-nofma", "achieved": round(achieved / 1e12, 3), "peak": round(FP64_VALU_PEAK / 1e12, 3), "unit": "Tops/s",
+                "frac": round(achieved / FP64_VALU_PEAK, 4), "traffic": None, "kernel": kernel, "avg_launch_ms": round(1e3 * launch_s, 3),
+                "peak_is": "%d CU x %d SIMD x %d DP lanes/clk x %.1f GHz (MI355X_MICROARCH.md max clock)" % (CUS, SIMDS_PER_CU, DP_LANES_PER_CLK, CLOCK_HZ / 1e9),
+                "dp_wave_instr_per_gate": dp_gate, "dp_wave_instr_per_cmux": ops, "gates_per_launch": G,
+                "launches_per_batch": round(launches / args.steps, 2),
+                # SURVEY 8(d)'s streaming model, kept for the record: it is NOT a bound for a batch that shares bk_i through L2
+                "hbm_algorithmic": {"bytes_per_gate": ALG_BYTES_PER_GATE, "GBps": round(ALG_BYTES_PER_GATE * G / launch_s / 1e9, 2),
+                                    "vs_hbm_peak": round(ALG_BYTES_PER_GATE * G / launch_s / HBM_PEAK, 4), "hbm_peak_GBps": HBM_PEAK / 1e9},
+            }
+        else:
+            achieved = ALG_BYTES_PER_GATE * G / launch_s
+            line["roofline"] = {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                "frac": round(achieved / HBM_PEAK, 4), "traffic": None, "kernel": kernel, "avg_launch_ms": round(1e3 * launch_s, 3),
+                                "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G, "launches_per_batch": round(launches / args.steps, 2)}
+        # measured HBM-side bytes per launch (rocprofv3 --pmc passes): only from a profile of THIS device code and launch shape
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 j = json.load(f)
-            if j.get("gates_per_launch") == G and args.backend == "fft64-mirror":
+            if j.get("gates_per_launch") == G and j.get("kernel") == kernel and j.get("src_hash") == kernel_src_hash():
                 line["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
-        if world == 1 and not args.no_cpu_baseline and args.backend == "fft64-mirror":
+                line["roofline"]["traffic_source"] = j.get("source")
+            else:
+                line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json is from other device code or another launch shape: not quoted"
+        if n_gpus == 1 and not args.no_cpu_baseline and mirror and not config3:
             line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
+                    help="config2 (default, BASELINE configs[1]): independent 1024-gate batches per GPU; config3 (BASELINE configs[2]): "
+                         "8192 gates per GPU scattered from / gathered to rank 0 inside the timed step")
+    ap.add_argument("--gates", type=int, default=0, help="gates per GPU per step (default 1024, config3: 8192)")
+    ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact"], default="fft64-mirror",
+                    help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-gates-per-thread", type=int, default=24)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args))                      # parent: spawn the ranks, never touch the GPU
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used\n" % (args.gpus, os.environ["WORLD_SIZE"]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -551,6 +551,7 @@ void orc_mux(const orc_params *p, orc_plan *pl, const double *bk_f, const uint32
 typedef struct {
     const orc_params *p; int backend; int op; const double *bk_f; const uint32_t *bk_t; const uint32_t *ksk;
     const uint32_t *in0, *in1; uint32_t *out; size_t begin, end;
+    pthread_barrier_t *ready;   /* every worker + the timing thread: plans exist, nothing has been computed yet */
 } mt_job;
 
 /* optional: every worker thread gets its own handle of an external transform (the reference's Spqlios_new /
@@ -566,27 +567,35 @@ static void *mt_worker(void *arg) {
     orc_plan_set_backend(pl, j->backend);
     if (j->backend == ORC_BACKEND_HOOK && g_mt_new) orc_plan_set_hooks(pl, g_mt_new(j->p->N), g_mt_fwd, g_mt_inv);
     const size_t w = (size_t)j->p->n + 1;
+    pthread_barrier_wait(j->ready);
     for (size_t g = j->begin; g < j->end; g++)
         orc_gate(j->p, pl, j->op, j->bk_f, j->bk_t, j->ksk, j->in0 + g * w, j->in1 ? j->in1 + g * w : NULL, j->out + g * w);
     orc_plan_free(pl);
     return NULL;
 }
 
+/* count gates on nthreads threads, one contiguous range and one plan (the reference: one Spqlios handle) per thread.
+ * Returns the seconds from the moment every thread holds its plan to the last thread's last gate: thread and plan
+ * creation (table building, libm) stay outside the timed region, as they are outside the reference's own timeit!. */
 double orc_gate_batch_mt(const orc_params *p, int backend, int op, const double *bk_f, const uint32_t *bk_t,
                          const uint32_t *ksk, const uint32_t *in0, const uint32_t *in1, uint32_t *out,
                          size_t count, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
     mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)nthreads);
+    pthread_barrier_t ready;
+    pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1u);
     struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < nthreads; t++) {
         jobs[t] = (mt_job){p, backend, op, bk_f, bk_t, ksk, in0, in1, out,
-                           count * (size_t)t / (size_t)nthreads, count * (size_t)(t + 1) / (size_t)nthreads};
+                           count * (size_t)t / (size_t)nthreads, count * (size_t)(t + 1) / (size_t)nthreads, &ready};
         pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
     }
+    pthread_barrier_wait(&ready);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    pthread_barrier_destroy(&ready);
     free(th); free(jobs);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

@@ -40,6 +40,28 @@ for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv
     for k, v in acc.items():
         summary["pmc"][k] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
 
+# Measured HBM-side bytes per launch of the bootstrap kernel, corrected as MI355X_MICROARCH.md's HBM section prescribes:
+# FETCH_SIZE (KiB-unit counter) doubled on gfx950 for 16-B-per-lane coalesced reads, WRITE_SIZE as is; separate --pmc
+# passes.  Stamped with the kernel name and a hash of the device sources so that bench.py only quotes it for the code it
+# was measured on (copy it to profiles/pmc_traffic.json together with the summary).
+sys.path.insert(0, root)
+import bench  # noqa: E402  (launcher half only: no torch, no HIP)
+names = [k for k in summary["kernels"] if "k_bootstrap" in k]
+if "FETCH_SIZE" in summary["pmc"] and "WRITE_SIZE" in summary["pmc"] and names:
+    fetch_kb, write_kb = summary["pmc"]["FETCH_SIZE"]["per_launch_mean"], summary["pmc"]["WRITE_SIZE"]["per_launch_mean"]
+    gates = int(os.environ.get("RTFHE_PROF_GATES", "1024"))
+    traffic = {
+        "gates_per_launch": gates, "kernel": names[0].split("<")[0].split("::")[-1],
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+        "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb, "src_hash": bench.kernel_src_hash(),
+        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 reports 1/2 of 16B/lane coalesced reads); WRITE_SIZE exact; "
+                "separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline`, mean over all its launches",
+        "source": "profiles/%s/summary.json" % tag,
+    }
+    summary["pmc_traffic"] = traffic
+    with open(os.path.join(dst, "pmc_traffic.json"), "w") as o:
+        json.dump(traffic, o, indent=1)
+
 with open(os.path.join(dst, "summary.json"), "w") as o:
     json.dump(summary, o, indent=1)
 print(json.dumps({k: summary[k] for k in summary if k != "kernels"}, indent=1)[:3000])

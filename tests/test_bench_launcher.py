@@ -1,0 +1,103 @@
+"""CPU: bench.py's own rank launcher (`python bench.py --gpus N` must start N ranks itself) and the bookkeeping behind
+the roofline line (FP64 wave-instruction count derived from the transform structure vs the ISA of the built kernel)."""
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHILD = r'''
+import json, os, sys
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo")
+t = torch.tensor([rank + 1.0])
+dist.all_reduce(t)
+if rank == 0:
+    print(json.dumps({"n_gpus": dist.get_world_size(), "sum": float(t[0])}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_spawn_ranks_sets_env_and_relays_rank0(tmp_path, capsys):
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(CHILD)
+    rc, lines = bench.spawn_ranks(2, [sys.executable, str(child)], timeout=240)
+    assert rc == 0
+    got = [json.loads(ln) for ln in lines if ln.startswith("{")]
+    assert got == [{"n_gpus": 2, "sum": 3.0}]
+    assert '"n_gpus": 2' in capsys.readouterr().out          # relayed to our own stdout
+
+
+def test_spawn_ranks_fails_when_any_rank_fails(tmp_path):
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(600)\n")
+    t0 = time.time()
+    rc, lines = bench.spawn_ranks(2, [sys.executable, str(child)], timeout=240)
+    assert rc == 3 and time.time() - t0 < 60                  # the surviving rank was terminated, not waited for
+
+
+def test_bare_bench_gpus2_launches_children_and_reports_their_failure():
+    """No GPU here: both children must come up as ranks (own env) and refuse loudly; the parent exits non-zero without
+    printing a JSON line of its own -- and without importing torch."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "rank" in r.stderr and "needs a GPU" in r.stderr
+    assert "{" not in r.stdout
+
+
+def test_parent_does_not_import_torch_before_spawning():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def run_rank")]
+    assert not re.search(r"^\s*import torch|^\s*from torch|import rustfhe_amd", head.replace("    import torch, torch", ""), re.M), \
+        "the launcher half of bench.py must not import torch or the HIP library"
+
+
+def test_dp_opcount_formula():
+    import bench
+    ops = bench.dp_wave_instr_per_cmux(1024, 3)
+    assert ops["transform"] == 360 and ops["mac_row"] == 64
+    assert ops["total"] == 3808 and ops["add_mul"] == 3680 and ops["cvt_trunc"] == 128
+    assert bench.dp_wave_instr_per_cmux(2048, 3)["transform"] == 800
+    assert abs(bench.FP64_VALU_PEAK - 39.3216e12) < 1e6
+    assert bench.ALG_BYTES_PER_GATE == 78061008
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_dp_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
+    """The count behind roofline.achieved is not a literal: the formula must agree with the v_add/v_mul_f64 (+ cvt/trunc)
+    instructions hipcc emits for k_bootstrap_pair's step loop.  The loop body holds slot P (side 0 only), slot Q (both)
+    and slot R (side 1 only): a wave executes all of it but one three-row slot, so static = per-wave + 3 MAC rows."""
+    import bench
+    from rustfhe_amd import build as b
+    asm = tmp_path / "api.s"
+    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + \
+          ["--cuda-device-only", "-S", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"), "-o", str(asm)]
+    subprocess.check_call(cmd)
+    text = asm.read_text()
+    m = re.search(r"\n(_ZN5rtfhe16k_bootstrap_pair\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S)
+    assert m, "k_bootstrap_pair not found in the device assembly"
+    body = m.group(2)
+    arith = len(re.findall(r"^\s*v_(?:add|mul)_f64", body, re.M))
+    fused = len(re.findall(r"^\s*v_fma_f64", body, re.M))
+    cvt = len(re.findall(r"^\s*v_(?:cvt_f64_i32|trunc_f64)", body, re.M))
+    assert fused == 0, "-ffp-contract=off is what parity rests on"
+    ops = bench.dp_wave_instr_per_cmux(1024, 3)
+    per_wave_arith, per_wave_cvt = ops["add_mul"] // 2, ops["cvt_trunc"] // 2
+    assert arith == per_wave_arith + 3 * ops["mac_row"], (arith, per_wave_arith)
+    assert cvt == per_wave_cvt, (cvt, per_wave_cvt)

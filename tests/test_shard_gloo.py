@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, count, q):
+def _worker(rank, world, port, count, q, op_name="NAND"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -47,13 +47,17 @@ def _worker(rank, world, port, count, q):
         bits = (rng.integers(0, 2, count), rng.integers(0, 2, count))
         in0 = torch.from_numpy(K.encrypt_bits(bits[0]).view(np.int32))
         in1 = torch.from_numpy(K.encrypt_bits(bits[1]).view(np.int32))
-    out = sg.run(orc.NAND, in0, in1, count)
+    op = getattr(orc, op_name)
+    unary = op_name in ("NOT", "COPY")
+    out = sg.run(op, in0, None if unary else in1, count, sync=(lambda: None))
+    assert set(sg.last_timing) == {"scatter_s", "compute_s", "gather_s"}
     res = None
     if rank == 0:
         o = out.numpy().view(np.uint32)
-        exp = np.stack([orc.gate(P, pl, orc.NAND, K.bk_f, None, K.ksk, x, y)
-                        for x, y in zip(in0.numpy().view(np.uint32), in1.numpy().view(np.uint32))])
-        res = (bool(np.array_equal(o, exp)), K.decrypt_bits(o) == list(1 - (bits[0] & bits[1])), partition(count, world))
+        a0 = in0.numpy().view(np.uint32)
+        exp = np.stack([orc.gate(P, pl, op, K.bk_f, None, K.ksk, x, y) for x, y in zip(a0, a0 if unary else in1.numpy().view(np.uint32))])
+        want = {"NAND": 1 - (bits[0] & bits[1]), "NOT": 1 - bits[0], "COPY": bits[0]}[op_name]
+        res = (bool(np.array_equal(o, exp)), K.decrypt_bits(o) == list(want), partition(count, world))
     else:
         assert out is None
     dist.barrier()
@@ -62,12 +66,13 @@ def _worker(rank, world, port, count, q):
         q.put(res)
 
 
-@pytest.mark.parametrize("count", [7, 2, 1])
-def test_scatter_bootstrap_gather_world2(count):
+@pytest.mark.parametrize("count,op_name", [(7, "NAND"), (2, "NAND"), (1, "NAND"), (5, "NOT")])
+def test_scatter_bootstrap_gather_world2(count, op_name):
+    """op NOT: a unary gate has no second input -- every rank must learn that from the root (it used to deadlock)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, count, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, count, q, op_name)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)
