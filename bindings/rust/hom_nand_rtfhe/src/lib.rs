@@ -31,11 +31,12 @@ pub struct TFHE<const TLWE_N: usize, const TRLWE_N: usize> { ctx: *mut sys::rtfh
 
 impl<const TLWE_N: usize, const TRLWE_N: usize> TFHE<TLWE_N, TRLWE_N> {
     /// `TFHE::new(s_key_tlwelv0, s_key_tlwelv1)` (tfhe.rs:21-25): generates KSK and BK for the given secret keys
-    /// (host side, seeded) and loads them on GPU 0.
+    /// (host side; masks and noise from the OS CSPRNG, as the reference draws from thread_rng) and loads them on GPU 0.
     pub fn new(s_key_tlwelv0: [Binary; TLWE_N], s_key_tlwelv1: [Binary; TRLWE_N]) -> Self {
-        Self::with_device(s_key_tlwelv0, s_key_tlwelv1, 0, 1)
+        Self::with_device(s_key_tlwelv0, s_key_tlwelv1, 0, None)
     }
-    pub fn with_device(s0: [Binary; TLWE_N], s1: [Binary; TRLWE_N], device: i32, key_seed: u64) -> Self {
+    /// `key_seed = Some(seed)` is TEST ONLY: reproducible, not secure (rtfhe_keygen_with_keys_deterministic).
+    pub fn with_device(s0: [Binary; TLWE_N], s1: [Binary; TRLWE_N], device: i32, key_seed: Option<u64>) -> Self {
         let mut p = sys::rtfhe_params { n: 0, N: 0, nbit: 0, l: 0, bgbit: 0, ks_t: 0, ks_basebit: 0 };
         unsafe { sys::rtfhe_default_params(&mut p) };
         p.n = TLWE_N as i32; p.N = TRLWE_N as i32; p.nbit = (TRLWE_N as u32).trailing_zeros() as i32;
@@ -45,7 +46,10 @@ impl<const TLWE_N: usize, const TRLWE_N: usize> TFHE<TLWE_N, TRLWE_N> {
         let mut ksk = vec![0u32; TRLWE_N * p.ks_t as usize * ((1usize << p.ks_basebit) - 1) * (TLWE_N + 1)];
         let mut ctx: *mut sys::rtfhe_ctx = std::ptr::null_mut();
         unsafe {
-            Self::check(std::ptr::null(), sys::rtfhe_keygen_with_keys(&p, key_seed, k0.as_ptr(), k1.as_ptr(), bk.as_mut_ptr(), ksk.as_mut_ptr()));
+            Self::check(std::ptr::null(), match key_seed {
+                None => sys::rtfhe_keygen_with_keys(&p, k0.as_ptr(), k1.as_ptr(), bk.as_mut_ptr(), ksk.as_mut_ptr()),
+                Some(seed) => sys::rtfhe_keygen_with_keys_deterministic(&p, seed, k0.as_ptr(), k1.as_ptr(), bk.as_mut_ptr(), ksk.as_mut_ptr()),
+            });
             Self::check(std::ptr::null(), sys::rtfhe_ctx_create(&p, device as c_int, &mut ctx));
             Self::check(ctx, sys::rtfhe_load_bk_torus(ctx, bk.as_ptr()));
             Self::check(ctx, sys::rtfhe_load_ksk(ctx, ksk.as_ptr()));

@@ -68,9 +68,14 @@ extern "C" {
     pub fn rtfhe_ifft_i32_batch(ctx: *mut rtfhe_ctx, src: *const i32, res: *mut f64, count: usize) -> c_int;
     pub fn rtfhe_fft_u32_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut u32, count: usize) -> c_int;
 
-    pub fn rtfhe_keygen(p: *const rtfhe_params, seed: u64, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;
-    pub fn rtfhe_keygen_with_keys(p: *const rtfhe_params, seed: u64, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
-    pub fn rtfhe_tlwe_encrypt_bits(p: *const rtfhe_params, key0: *const i32, seed: u64, bits: *const u8, out: *mut u32, count: usize) -> c_int;
+    // production: randomness from the OS CSPRNG (like the reference's thread_rng)
+    pub fn rtfhe_keygen(p: *const rtfhe_params, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_keygen_with_keys(p: *const rtfhe_params, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_tlwe_encrypt_bits(p: *const rtfhe_params, key0: *const i32, bits: *const u8, out: *mut u32, count: usize) -> c_int;
+    // TEST ONLY (seeded xoshiro256**, not secure)
+    pub fn rtfhe_keygen_deterministic(p: *const rtfhe_params, seed: u64, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_keygen_with_keys_deterministic(p: *const rtfhe_params, seed: u64, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
+    pub fn rtfhe_tlwe_encrypt_bits_deterministic(p: *const rtfhe_params, key0: *const i32, seed: u64, bits: *const u8, out: *mut u32, count: usize) -> c_int;
     pub fn rtfhe_tlwe_decrypt_bits(p: *const rtfhe_params, key0: *const i32, input: *const u32, bits: *mut u8, count: usize) -> c_int;
     pub fn rtfhe_keys_write(path: *const c_char, p: *const rtfhe_params, key0: *const i32, key1: *const i32, bk: *const u32, ksk: *const u32) -> c_int;
     pub fn rtfhe_keys_read_header(path: *const c_char, p: *mut rtfhe_params, flags: *mut u32) -> c_int;

@@ -20,7 +20,8 @@
  *   rtfhe_ifft_i32_batch             <- Spqlios_ifft_i32 / _u32 (utils/src/spqlios.rs:22-23, spqlios-wrapper.cpp:22-28)
  *   rtfhe_fft_u32_batch              <- Spqlios_fft_u32 (utils/src/spqlios.rs:25, spqlios-wrapper.cpp:34-36)
  *   rtfhe_keys_* / rtfhe_tlwe_write/read  (no reference counterpart: it has no serialization; fixes App. A's layouts into files)
- *   rtfhe_keygen / rtfhe_tlwe_*      <- TFHE::new, Cryptor::encrypto/decrypto(TLWE, ..) (tfhe.rs:21-25, tlwe.rs:213-241)
+ *   rtfhe_keygen / rtfhe_tlwe_*      <- TFHE::new, Cryptor::encrypto/decrypto(TLWE, ..) (tfhe.rs:21-25, tlwe.rs:213-241);
+ *                                       randomness from the OS CSPRNG like the reference's thread_rng; *_deterministic = seeded, TEST ONLY
  *
  * Conventions: every call returns 0 on success or a negative rtfhe_status; nothing aborts or throws
  * across the ABI; rtfhe_last_error() gives the message of the last failure on that context.  The caller
@@ -138,13 +139,23 @@ int rtfhe_key_switch_batch(rtfhe_ctx *ctx, const uint32_t *tlwe1 /* [count][N+1]
 int rtfhe_ifft_i32_batch(rtfhe_ctx *ctx, const int32_t *src /* [count][N] */, double *res /* [count][N] */, size_t count);
 int rtfhe_fft_u32_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, uint32_t *res /* [count][N] */, size_t count);
 
-/* ---- key generation / encryption (host side; own seeded generator, the reference's is thread_rng) ---- */
-int rtfhe_keygen(const rtfhe_params *p, uint64_t seed, int32_t *key0 /* [n] */, int32_t *key1 /* [N] */,
+/* ---- key generation / encryption (host side) ----
+ * Production entry points draw every key bit, mask and noise sample from the OS CSPRNG (getrandom(2), expanded with ChaCha20),
+ * as the reference draws from rand::thread_rng (utils/src/math.rs:417-479).  They fail with RTFHE_ERR_STATE if the OS gives
+ * no entropy.  rtfhe_keygen_with_keys is TFHE::new for caller-supplied secret keys (hom_nand/src/tfhe.rs:21-25). */
+int rtfhe_keygen(const rtfhe_params *p, int32_t *key0 /* [n] */, int32_t *key1 /* [N] */,
                  uint32_t *bk /* [n][2][2l][N] */, uint32_t *ksk /* [N][t][base-1][n+1] */);
-int rtfhe_keygen_with_keys(const rtfhe_params *p, uint64_t seed, const int32_t *key0, const int32_t *key1,
-                           uint32_t *bk, uint32_t *ksk);    /* TFHE::new for caller-supplied secret keys */
-int rtfhe_tlwe_encrypt_bits(const rtfhe_params *p, const int32_t *key0, uint64_t seed,
-                            const uint8_t *bits, uint32_t *out /* [count][n+1] */, size_t count);
+int rtfhe_keygen_with_keys(const rtfhe_params *p, const int32_t *key0, const int32_t *key1, uint32_t *bk, uint32_t *ksk);
+int rtfhe_tlwe_encrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint8_t *bits, uint32_t *out /* [count][n+1] */,
+                            size_t count);
+/* TEST ONLY -- NOT SECURE: the same, reproducible from a 64-bit seed expanded through xoshiro256** (not a CSPRNG: whoever knows
+ * the seed regenerates every mask and noise sample and recovers the secret key from the key-switching key; a reused seed
+ * reuses mask and noise).  For fixtures, parity tests and benchmarks only; never for keys or ciphertexts that protect data. */
+int rtfhe_keygen_deterministic(const rtfhe_params *p, uint64_t seed, int32_t *key0, int32_t *key1, uint32_t *bk, uint32_t *ksk);
+int rtfhe_keygen_with_keys_deterministic(const rtfhe_params *p, uint64_t seed, const int32_t *key0, const int32_t *key1,
+                                         uint32_t *bk, uint32_t *ksk);
+int rtfhe_tlwe_encrypt_bits_deterministic(const rtfhe_params *p, const int32_t *key0, uint64_t seed,
+                                          const uint8_t *bits, uint32_t *out /* [count][n+1] */, size_t count);
 int rtfhe_tlwe_decrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint32_t *in,
                             uint8_t *bits, size_t count);
 int rtfhe_tlwe_phase(const rtfhe_params *p, const int32_t *key0, const uint32_t *in, uint32_t *phase, size_t count);

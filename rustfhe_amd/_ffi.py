@@ -61,9 +61,12 @@ _SIGNATURES = {
     "rtfhe_key_switch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_ifft_i32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_fft_u32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
-    "rtfhe_keygen": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "rtfhe_keygen_with_keys": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_keygen": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_keygen_with_keys": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_keygen_deterministic": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_keygen_with_keys_deterministic": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_tlwe_encrypt_bits_deterministic": (C.c_int, ["PP", C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_tlwe_decrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_tlwe_phase": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_keys_write": (C.c_int, [C.c_char_p, "PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

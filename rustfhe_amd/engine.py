@@ -182,24 +182,33 @@ class Engine:
 
 # ---- host-side key generation / encryption (C ABI, no GPU needed) --------------------------------
 
-def keygen(params, seed, want_bk=True, want_ksk=True):
+def keygen(params, seed=None, want_bk=True, want_ksk=True):
+    """seed None (production): every key bit, mask and noise sample comes from the OS CSPRNG.  An integer seed selects the
+    TEST-ONLY deterministic generator (rtfhe_keygen_deterministic: reproducible, NOT secure)."""
     L = _ffi.load()
     key0 = np.empty(params.n, np.int32)
     key1 = np.empty(params.N, np.int32)
     bk = np.empty(params.bk_words, np.uint32) if want_bk else None
     ksk = np.empty(params.ksk_words, np.uint32) if want_ksk else None
-    rc = L.rtfhe_keygen(C.byref(params), seed, _ptr(key0), _ptr(key1), _ptr(bk), _ptr(ksk))
+    if seed is None:
+        rc = L.rtfhe_keygen(C.byref(params), _ptr(key0), _ptr(key1), _ptr(bk), _ptr(ksk))
+    else:
+        rc = L.rtfhe_keygen_deterministic(C.byref(params), seed, _ptr(key0), _ptr(key1), _ptr(bk), _ptr(ksk))
     if rc != 0:
         raise RtfheError(rc, "rtfhe_keygen failed")
     return key0, key1, bk, ksk
 
 
-def encrypt_bits(params, key0, bits, seed):
+def encrypt_bits(params, key0, bits, seed=None):
+    """seed None (production): mask and noise from the OS CSPRNG; an integer seed = TEST-ONLY deterministic encryption."""
     L = _ffi.load()
     bits = _np(bits, np.uint8).reshape(-1)
     key0 = _np(key0, np.int32)
     out = np.empty((bits.size, params.n + 1), np.uint32)
-    rc = L.rtfhe_tlwe_encrypt_bits(C.byref(params), _ptr(key0), seed, _ptr(bits), _ptr(out), bits.size)
+    if seed is None:
+        rc = L.rtfhe_tlwe_encrypt_bits(C.byref(params), _ptr(key0), _ptr(bits), _ptr(out), bits.size)
+    else:
+        rc = L.rtfhe_tlwe_encrypt_bits_deterministic(C.byref(params), _ptr(key0), seed, _ptr(bits), _ptr(out), bits.size)
     if rc != 0:
         raise RtfheError(rc, "rtfhe_tlwe_encrypt_bits failed")
     return out

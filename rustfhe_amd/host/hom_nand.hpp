@@ -70,14 +70,23 @@ struct TLWERep {
 
 struct TLWE {};   // strategy marker, hom_nand/src/tlwe.rs:10
 
-// Cryptor::encrypto / decrypto (digest.rs:19-34) for the TLWE strategy; seeded (the reference uses thread_rng)
+// Cryptor::encrypto / decrypto (digest.rs:19-34) for the TLWE strategy.  encrypto draws from the OS CSPRNG like the
+// reference's thread_rng; encrypto_deterministic(.., seed) is the seeded TEST-ONLY form (not secure).
 struct Cryptor {
     template <int N>
-    static TLWERep<N> encrypto(TLWE, const std::array<Binary, N>& s_key, Binary item, uint64_t seed) {
+    static TLWERep<N> encrypto(TLWE, const std::array<Binary, N>& s_key, Binary item) {
         rtfhe_params p; rtfhe_default_params(&p); p.n = N;
         std::vector<int32_t> k(N); for (int i = 0; i < N; i++) k[i] = (int32_t)s_key[i];
         uint8_t bit = item == Binary::One; std::vector<uint32_t> out(N + 1);
-        if (rtfhe_tlwe_encrypt_bits(&p, k.data(), seed, &bit, out.data(), 1)) throw std::runtime_error("rtfhe_tlwe_encrypt_bits");
+        if (rtfhe_tlwe_encrypt_bits(&p, k.data(), &bit, out.data(), 1)) throw std::runtime_error("rtfhe_tlwe_encrypt_bits");
+        return TLWERep<N>::from_flat(out.data());
+    }
+    template <int N>
+    static TLWERep<N> encrypto_deterministic(TLWE, const std::array<Binary, N>& s_key, Binary item, uint64_t seed) {
+        rtfhe_params p; rtfhe_default_params(&p); p.n = N;
+        std::vector<int32_t> k(N); for (int i = 0; i < N; i++) k[i] = (int32_t)s_key[i];
+        uint8_t bit = item == Binary::One; std::vector<uint32_t> out(N + 1);
+        if (rtfhe_tlwe_encrypt_bits_deterministic(&p, k.data(), seed, &bit, out.data(), 1)) throw std::runtime_error("rtfhe_tlwe_encrypt_bits_deterministic");
         return TLWERep<N>::from_flat(out.data());
     }
     template <int N>
@@ -103,21 +112,30 @@ template <int TLWE_N = TLWEHelper::N, int TRLWE_N = TRLWEHelper::N>
 class TFHE : public Logip<TLWERep<TLWE_N>> {
   public:
     using Rep = TLWERep<TLWE_N>;
-    // TFHE::new (tfhe.rs:21-25): generates KSK and BK for the given secret keys and loads them on `device`.
-    // key_seed seeds the encryption randomness of the key material (the reference draws from thread_rng).
-    TFHE(const std::array<Binary, TLWE_N>& s_key_tlwelv0, const std::array<Binary, TRLWE_N>& s_key_tlwelv1,
-         uint64_t key_seed = 1, int device = 0) {
+    // TFHE::new (tfhe.rs:21-25): generates KSK and BK for the given secret keys and loads them on `device`.  The key
+    // material's masks and noise come from the OS CSPRNG (the reference draws from thread_rng).
+    TFHE(const std::array<Binary, TLWE_N>& s_key_tlwelv0, const std::array<Binary, TRLWE_N>& s_key_tlwelv1, int device = 0)
+        : TFHE(s_key_tlwelv0, s_key_tlwelv1, device, nullptr) {}
+    // TEST ONLY (not secure): key material reproducible from `key_seed` (rtfhe_keygen_with_keys_deterministic)
+    static TFHE new_deterministic(const std::array<Binary, TLWE_N>& s_key_tlwelv0, const std::array<Binary, TRLWE_N>& s_key_tlwelv1,
+                                  uint64_t key_seed, int device = 0) {
+        return TFHE(s_key_tlwelv0, s_key_tlwelv1, device, &key_seed);
+    }
+
+  private:
+    TFHE(const std::array<Binary, TLWE_N>& s_key_tlwelv0, const std::array<Binary, TRLWE_N>& s_key_tlwelv1, int device,
+         const uint64_t* key_seed) {
         rtfhe_default_params(&p_);
         p_.n = TLWE_N; p_.N = TRLWE_N; p_.nbit = 0;
         for (int v = TRLWE_N; v > 1; v >>= 1) p_.nbit++;
-        // rtfhe_keygen draws its own secret keys from the seed; to honour caller-supplied keys the key material is
-        // generated against them: keygen is run for the bk/ksk buffers with the secret keys passed in.
+        // rtfhe_keygen draws its own secret keys; to honour caller-supplied keys the key material is generated against them
         std::vector<int32_t> k0(TLWE_N), k1(TRLWE_N);
         for (int i = 0; i < TLWE_N; i++) k0[i] = (int32_t)s_key_tlwelv0[i];
         for (int i = 0; i < TRLWE_N; i++) k1[i] = (int32_t)s_key_tlwelv1[i];
         std::vector<uint32_t> bk((size_t)TLWE_N * 2 * 2 * p_.l * TRLWE_N);
         std::vector<uint32_t> ksk((size_t)TRLWE_N * p_.ks_t * ((1 << p_.ks_basebit) - 1) * (TLWE_N + 1));
-        check(nullptr, rtfhe_keygen_with_keys(&p_, key_seed, k0.data(), k1.data(), bk.data(), ksk.data()));
+        check(nullptr, key_seed ? rtfhe_keygen_with_keys_deterministic(&p_, *key_seed, k0.data(), k1.data(), bk.data(), ksk.data())
+                                : rtfhe_keygen_with_keys(&p_, k0.data(), k1.data(), bk.data(), ksk.data()));
         rtfhe_ctx* c = nullptr;
         check(nullptr, rtfhe_ctx_create(&p_, device, &c));
         ctx_.reset(c, rtfhe_ctx_destroy);
@@ -125,6 +143,7 @@ class TFHE : public Logip<TLWERep<TLWE_N>> {
         check(c, rtfhe_load_ksk(c, ksk.data()));
     }
 
+  public:
     Rep hom_nand(const Rep& a, const Rep& b) const { return one(RTFHE_NAND, a, &b); }   // tfhe.rs:41-47
     Rep hom_and(const Rep& a, const Rep& b) const { return one(RTFHE_AND, a, &b); }     // tfhe.rs:48-54
     Rep hom_or(const Rep& a, const Rep& b) const { return one(RTFHE_OR, a, &b); }       // tfhe.rs:55-61

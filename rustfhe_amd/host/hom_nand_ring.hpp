@@ -97,11 +97,13 @@ struct TRGSWRep {
     static constexpr int ROWS = 2 * TRGSWHelper::L;
     std::array<Polynomial<N>, ROWS> cipher_, p_key_;
     // Crypto<i32> / Crypto<Binary> for TRGSW (trgsw.rs:217-229): produced by the library's key generator with n = 1
-    static TRGSWRep encrypto(const std::array<Binary, N>& s_key, Binary item, uint64_t seed) {
+    // seed: TEST ONLY (rtfhe_keygen_with_keys_deterministic); nullptr = OS CSPRNG like the reference's thread_rng
+    static TRGSWRep encrypto(const std::array<Binary, N>& s_key, Binary item, const uint64_t* seed = nullptr) {
         rtfhe_params p; rtfhe_default_params(&p); p.n = 1; p.N = N; p.nbit = 0; for (int v = N; v > 1; v >>= 1) p.nbit++;
         int32_t k0 = (int32_t)item; std::vector<int32_t> k1(N); for (int i = 0; i < N; i++) k1[i] = (int32_t)s_key[i];
         std::vector<uint32_t> flat((size_t)2 * ROWS * N);
-        if (rtfhe_keygen_with_keys(&p, seed, &k0, k1.data(), flat.data(), nullptr)) throw std::runtime_error("TRGSW::encrypto");
+        if (seed ? rtfhe_keygen_with_keys_deterministic(&p, *seed, &k0, k1.data(), flat.data(), nullptr)
+                 : rtfhe_keygen_with_keys(&p, &k0, k1.data(), flat.data(), nullptr)) throw std::runtime_error("TRGSW::encrypto");
         TRGSWRep r;
         for (int j = 0; j < ROWS; j++) for (int k = 0; k < N; k++) { r.cipher_[j][k] = flat[(size_t)j * N + k]; r.p_key_[j][k] = flat[((size_t)ROWS + j) * N + k]; }
         return r;
@@ -142,13 +144,15 @@ class TRGSWRepF {
 template <int PRE_N, int N>
 struct BootstrappingKey {
     std::vector<uint32_t> flat;       // [PRE_N][2][2l][N]
-    BootstrappingKey(const std::array<Binary, PRE_N>& s_key_tlwe, const std::array<Binary, N>& s_key, uint64_t seed = 1) {
+    // seed: TEST ONLY (deterministic, not secure); nullptr = OS CSPRNG
+    BootstrappingKey(const std::array<Binary, PRE_N>& s_key_tlwe, const std::array<Binary, N>& s_key, const uint64_t* seed = nullptr) {
         rtfhe_params p; rtfhe_default_params(&p); p.n = PRE_N; p.N = N; p.nbit = 0; for (int v = N; v > 1; v >>= 1) p.nbit++;
         std::vector<int32_t> k0(PRE_N), k1(N);
         for (int i = 0; i < PRE_N; i++) k0[i] = (int32_t)s_key_tlwe[i];
         for (int i = 0; i < N; i++) k1[i] = (int32_t)s_key[i];
         flat.resize((size_t)PRE_N * 2 * 2 * p.l * N);
-        if (rtfhe_keygen_with_keys(&p, seed, k0.data(), k1.data(), flat.data(), nullptr)) throw std::runtime_error("BootstrappingKey::new");
+        if (seed ? rtfhe_keygen_with_keys_deterministic(&p, *seed, k0.data(), k1.data(), flat.data(), nullptr)
+                 : rtfhe_keygen_with_keys(&p, k0.data(), k1.data(), flat.data(), nullptr)) throw std::runtime_error("BootstrappingKey::new");
     }
     size_t size() const { return PRE_N; }
     const uint32_t* trgsw(int i) const { return flat.data() + (size_t)i * 2 * 2 * TRGSWHelper::L * N; }   // iter(): i-th TRGSW
@@ -158,13 +162,14 @@ struct BootstrappingKey {
 template <int N, int M>
 struct KeySwitchingKey {
     std::vector<uint32_t> flat;       // [N][IKS_L][IKS_T - 1][M + 1]
-    KeySwitchingKey(const std::array<Binary, N>& pre_s_key, const std::array<Binary, M>& next_s_key, uint64_t seed = 1) {
+    KeySwitchingKey(const std::array<Binary, N>& pre_s_key, const std::array<Binary, M>& next_s_key, const uint64_t* seed = nullptr) {
         rtfhe_params p; rtfhe_default_params(&p); p.n = M; p.N = N; p.nbit = 0; for (int v = N; v > 1; v >>= 1) p.nbit++;
         std::vector<int32_t> k0(M), k1(N);
         for (int i = 0; i < M; i++) k0[i] = (int32_t)next_s_key[i];
         for (int i = 0; i < N; i++) k1[i] = (int32_t)pre_s_key[i];
         flat.resize((size_t)N * TLWEHelper::IKS_L * (TLWEHelper::IKS_T - 1) * (M + 1));
-        if (rtfhe_keygen_with_keys(&p, seed, k0.data(), k1.data(), nullptr, flat.data())) throw std::runtime_error("KeySwitchingKey::new");
+        if (seed ? rtfhe_keygen_with_keys_deterministic(&p, *seed, k0.data(), k1.data(), nullptr, flat.data())
+                 : rtfhe_keygen_with_keys(&p, k0.data(), k1.data(), nullptr, flat.data())) throw std::runtime_error("KeySwitchingKey::new");
     }
     // get(i, l, t) = KS[i][l][t-1] = TLWE(t * s_i / 2^(bit (l+1)))   (tlwe.rs:281-283)
     TLWERep<M> get(int i, int l, int t) const {

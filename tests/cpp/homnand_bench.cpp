@@ -18,8 +18,14 @@ int main() {
     for (auto& b : s1) b = (rng() & 1) ? Binary::One : Binary::Zero;
     try {
         TFHE<TLWE_N, TRLWE_N> tfhe(s0, s1);
-        uint64_t seed = 100;
-        auto enc = [&](Binary b) { return Cryptor::encrypto<TLWE_N>(TLWE{}, s0, b, seed++); };
+        // production forms: key material and ciphertext randomness from the OS CSPRNG, like the reference's thread_rng
+        auto enc = [&](Binary b) { return Cryptor::encrypto<TLWE_N>(TLWE{}, s0, b); };
+        {   // two encryptions of the same bit never share mask or noise; the seeded TEST-ONLY form is reproducible
+            auto e1 = enc(Binary::One), e2 = enc(Binary::One);
+            if (e1 == e2) { std::printf("secure encryption repeated itself\n"); return 1; }
+            auto d1 = Cryptor::encrypto_deterministic<TLWE_N>(TLWE{}, s0, Binary::One, 100), d2 = Cryptor::encrypto_deterministic<TLWE_N>(TLWE{}, s0, Binary::One, 100);
+            if (!(d1 == d2)) { std::printf("deterministic encryption not reproducible\n"); return 1; }
+        }
         struct G { const char* title; int op; int tt[4]; };
         const G gates[] = {{"nand", 0, {1, 1, 1, 0}}, {"and", 1, {0, 0, 0, 1}}, {"or", 2, {0, 1, 1, 1}}, {"xor", 3, {0, 1, 1, 0}}};
         int bad = 0;
@@ -58,14 +64,15 @@ int main() {
             auto t1 = rep1.sample_extract_index(0);
             if ((int)Cryptor::decrypto<TRLWE_N>(TLWE{}, s1, t1) != 1) { std::printf("sample_extract WRONG\n"); bad++; }
             for (int bit = 0; bit < 2; bit++) {
-                TRGSWRepF<TRLWE_N> c(TRGSWRep<TRLWE_N>::encrypto(s1, bit ? Binary::One : Binary::Zero, 600 + bit));
+                TRGSWRepF<TRLWE_N> c(TRGSWRep<TRLWE_N>::encrypto(s1, bit ? Binary::One : Binary::Zero));
                 auto sel = c.cmux(rep1, rep0);                                   // TRGSW(i).cmux(rep_1, rep_0) = rep_i
                 auto ph = trlwe_decrypto<TRLWE_N>(s1, sel);
                 int wrong = 0;
                 for (int k = 0; k < TRLWE_N; k++) if ((int)TLWEHelper::torus2binary(ph[k]) != bit) wrong++;
                 if (wrong) { std::printf("cmux(%d) WRONG in %d coefficients\n", bit, wrong); bad++; }
             }
-            KeySwitchingKey<TRLWE_N, TLWE_N> ksk(s1, s0, 7);
+            const uint64_t ks_seed = 7;
+            KeySwitchingKey<TRLWE_N, TLWE_N> ksk(s1, s0, &ks_seed);
             auto row = ksk.get(3, 0, 1);                                         // TLWE(1 * s1[3] / 4)
             Torus32 s = 0; for (int i = 0; i < TLWE_N; i++) if (s0[i] == Binary::One) s += row.p_key()[i];
             const int32_t err = (int32_t)(row.cipher() - s - (s1[3] == Binary::One ? 0x40000000u : 0u));

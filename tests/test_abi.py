@@ -115,6 +115,34 @@ def test_host_keygen_encrypt_decrypt_roundtrip():
     assert np.array_equal(key0, k0b)
 
 
+def test_production_keygen_draws_from_the_os_csprng():
+    """rtfhe_keygen / rtfhe_tlwe_encrypt_bits (no seed) are the production forms: OS CSPRNG + ChaCha20, never repeatable;
+    the seeded xoshiro forms live under *_deterministic and are documented as test-only in include/rtfhe.h."""
+    import rustfhe_amd as R
+    p = R.Params(n=40)
+    a = R.keygen(p, want_bk=False, want_ksk=True)
+    b = R.keygen(p, want_bk=False, want_ksk=True)
+    assert not np.array_equal(a[0], b[0]) or not np.array_equal(a[1], b[1])          # 1064 fresh key bits
+    assert not np.array_equal(a[3], b[3])
+    key0, key1, _, ksk = a
+    assert set(np.unique(key0)) <= {0, 1} and 0.3 < key1.mean() < 0.7
+    bits = np.array([1, 0, 1, 1, 0, 0, 1, 0], np.uint8)
+    c1, c2 = R.encrypt_bits(p, key0, bits), R.encrypt_bits(p, key0, bits)
+    assert not np.array_equal(c1, c2)                                                 # masks and noise are never reused
+    assert np.array_equal(R.decrypt_bits(p, key0, c1), bits) and np.array_equal(R.decrypt_bits(p, key0, c2), bits)
+    # masks look uniform over the f32-derived torus grid (utils/src/math.rs:425-432: 24 random bits, low byte zero)
+    masks = c1[:, :p.n].reshape(-1)
+    assert (masks & 0xff).max() == 0 and len(np.unique(masks)) == masks.size
+    # key-switch rows are valid encryptions under the fresh keys (tlwe.rs:252-274)
+    rows = ksk.reshape(p.N, p.ks_t, 3, p.n + 1)
+    for (i, l, d) in [(1, 0, 0), (5, 3, 2)]:
+        got = int(R.phases(p, key0, rows[i, l, d][None])[0])
+        want = (d + 1) * int(key1[i]) * (1 << (32 - 2 * (l + 1))) % 2 ** 32
+        assert abs(((got - want + 2 ** 31) % 2 ** 32) - 2 ** 31) < 2 ** 21
+    hdr = open(os.path.join(ROOT, "include", "rtfhe.h")).read()
+    assert "TEST ONLY" in hdr and "rtfhe_keygen_deterministic" in hdr
+
+
 def test_host_bk_is_a_valid_trgsw_set(orc):
     """BK rows produced by the product's keygen decrypt (with the oracle as checker) to mu * 2^(32-6(i+1)) gadget rows."""
     import rustfhe_amd as R
