@@ -14,6 +14,7 @@ pub struct rtfhe_params {
     pub ks_basebit: i32, // key-switch base bits   hom_nand/src/tlwe.rs:179
 }
 pub enum rtfhe_ctx {}
+pub enum rtfhe_circuit {}
 
 pub const RTFHE_NAND: c_int = 0;
 pub const RTFHE_AND: c_int = 1;
@@ -36,6 +37,10 @@ pub const RTFHE_ERR_NOMEM: c_int = -5;
 extern "C" {
     pub fn rtfhe_default_params(p: *mut rtfhe_params);
     pub fn rtfhe_ctx_create(p: *const rtfhe_params, device_id: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
+    pub fn rtfhe_ctx_create_multi(p: *const rtfhe_params, device_ids: *const c_int, n_dev: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
+    pub fn rtfhe_ctx_device_count(ctx: *const rtfhe_ctx) -> c_int;
+    pub fn rtfhe_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn rtfhe_host_free(p: *mut c_void);
     pub fn rtfhe_ctx_destroy(ctx: *mut rtfhe_ctx);
     pub fn rtfhe_last_error(ctx: *const rtfhe_ctx) -> *const c_char;
     pub fn rtfhe_version() -> *const c_char;
@@ -58,6 +63,10 @@ extern "C" {
                                 count: usize, stream: *mut c_void) -> c_int;
     pub fn rtfhe_circuit_wave_dev(ctx: *mut rtfhe_ctx, d_ops: *const c_void, d_idx0: *const c_void, d_idx1: *const c_void,
                                   d_idx_out: *const c_void, d_wires: *mut c_void, num_wires: usize, count: usize, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_circuit_create(ctx: *mut rtfhe_ctx, d_ops: *const c_void, d_idx0: *const c_void, d_idx1: *const c_void, d_idx_out: *const c_void,
+                                wave_offsets: *const i32, num_waves: i32, d_wires: *mut c_void, num_wires: usize, out: *mut *mut rtfhe_circuit) -> c_int;
+    pub fn rtfhe_circuit_launch(c: *mut rtfhe_circuit, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_circuit_destroy(c: *mut rtfhe_circuit);
     pub fn rtfhe_sync(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
     pub fn rtfhe_timer_begin(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
     pub fn rtfhe_timer_end(ctx: *mut rtfhe_ctx, stream: *mut c_void, ms: *mut f64, launches: *mut i64) -> c_int;

@@ -6,6 +6,8 @@
  *
  *   rtfhe_ctx_create / _destroy      <- thread_local FFT_MAP + Spqlios_new / Spqlios_destructor
  *                                       (utils/src/math.rs:349-360, utils/src/spqlios.rs:18-20,139-145)
+ *   rtfhe_ctx_create_multi           <- (no reference counterpart: it is single-threaded, tlwe.rs:264 TODO) one context over the
+ *                                       GPUs of a node; the same batch calls then shard gates over them
  *   rtfhe_load_bk_torus              <- BootstrappingKey::new's TRGSWRepF::from (hom_nand/src/tfhe.rs:119-126,
  *                                       hom_nand/src/trgsw.rs:68-76)
  *   rtfhe_load_bk_fft                <- BootstrappingKey(Vec<TRGSWRepF>) as the reference holds it (tfhe.rs:116)
@@ -13,6 +15,7 @@
  *   rtfhe_gate_batch[_dev]           <- TFHE::hom_nand/and/or/xor/not (hom_nand/src/tfhe.rs:41-71), count gates at once
  *   rtfhe_mux_batch                  <- TFHE::hom_mux (tfhe.rs:27-40)
  *   rtfhe_circuit_wave_dev           <- eval_logic_expr over impl Logip for TFHE (nander/src/lib.rs:40-89), one level at a time
+ *   rtfhe_circuit_create / _launch   <- the same evaluation, all levels of a netlist recorded once and replayed as one submission
  *   rtfhe_bootstrap_batch            <- TFHE::bootstrap (tfhe.rs:73-80)
  *   rtfhe_blind_rotate_batch         <- TFHE::blind_rotate with the gate test vector (tfhe.rs:81-113)
  *   rtfhe_external_product_batch     <- Cross for TRGSWRepF (hom_nand/src/trgsw.rs:264-306)
@@ -27,7 +30,7 @@
  * across the ABI; rtfhe_last_error() gives the message of the last failure on that context.  The caller
  * owns every buffer.  Host-pointer calls copy in/out and are synchronous; *_dev calls take device
  * pointers, enqueue on the given hipStream_t (passed as void*) and return without synchronising.
- * A context is bound to one device and is not thread-safe (the reference's handle is not either:
+ * A context is bound to one device (rtfhe_ctx_create) or to a set of devices (rtfhe_ctx_create_multi) and is not thread-safe (the reference's handle is not either:
  * one per thread, utils/src/math.rs:349-351).  There is NO CPU fallback: without a usable HIP device
  * rtfhe_ctx_create fails with RTFHE_ERR_NO_DEVICE.
  *
@@ -88,7 +91,19 @@ typedef enum {
 /* ---- context ---- */
 void rtfhe_default_params(rtfhe_params *p);
 int rtfhe_ctx_create(const rtfhe_params *p, int device_id, rtfhe_ctx **out);
+/* One context over n_dev GPUs of the node (what a Rust `hom_nand_batch` binds for a whole-node batch).
+ * device_ids[0] is the primary.  Keys loaded into the context are transformed once on the primary and copied
+ * device-to-device to the others.  The host-pointer batch calls (rtfhe_gate_batch, rtfhe_mux_batch, rtfhe_bootstrap_batch)
+ * shard contiguous gate ranges over the devices -- device d gets [count d / n_dev, count (d+1) / n_dev) -- with one host
+ * thread and one stream per device and direct host<->device copies per device; outputs land at the same indices as on one
+ * device and are bit-identical.  *_dev and stage-level calls run on the primary device only. */
+int rtfhe_ctx_create_multi(const rtfhe_params *p, const int *device_ids, int n_dev, rtfhe_ctx **out);
+int rtfhe_ctx_device_count(const rtfhe_ctx *ctx);      /* devices behind this context (1 for rtfhe_ctx_create) */
 void rtfhe_ctx_destroy(rtfhe_ctx *ctx);
+/* pinned host memory for ciphertext buffers: host-pointer calls DMA straight from / into such a buffer; any other host
+ * pointer is staged through the context's own pinned buffers (one extra host copy) */
+void *rtfhe_host_alloc(size_t bytes);
+void rtfhe_host_free(void *p);
 const char *rtfhe_last_error(const rtfhe_ctx *ctx);   /* ctx may be NULL: last ctx-less error */
 const char *rtfhe_version(void);
 int rtfhe_device_count(void);
@@ -122,6 +137,15 @@ int rtfhe_gate_batch_dev(rtfhe_ctx *ctx, int op, const void *d_in0, const void *
  * it) and the next rtfhe_sync returns RTFHE_ERR_INVALID. */
 int rtfhe_circuit_wave_dev(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0, const void *d_idx1,
                            const void *d_idx_out, void *d_wires, size_t num_wires, size_t count, void *stream);
+/* A whole levelised netlist as ONE submission (BASELINE config 4; the reference walks its expression tree gate by gate,
+ * nander/src/lib.rs:72-89): the waves wave_offsets[w] .. wave_offsets[w+1] (host array, num_waves + 1 entries) of the same four
+ * device arrays are captured once into a HIP graph; rtfhe_circuit_launch replays it on `stream` (asynchronous, one runtime
+ * call per evaluation).  The device arrays and the wire table must stay alive and in place while the circuit exists. */
+typedef struct rtfhe_circuit rtfhe_circuit;
+int rtfhe_circuit_create(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0, const void *d_idx1, const void *d_idx_out,
+                         const int32_t *wave_offsets, int32_t num_waves, void *d_wires, size_t num_wires, rtfhe_circuit **out);
+int rtfhe_circuit_launch(rtfhe_circuit *c, void *stream);
+void rtfhe_circuit_destroy(rtfhe_circuit *c);
 /* waits for `stream`; also reports (once) a netlist gate skipped since the previous call */
 int rtfhe_sync(rtfhe_ctx *ctx, void *stream);
 /* device-side timing of the launches enqueued by the *_dev calls between begin and end (HIP events on

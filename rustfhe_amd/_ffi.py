@@ -36,7 +36,11 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -
 _SIGNATURES = {
     "rtfhe_default_params": (None, ["PP"]),
     "rtfhe_ctx_create": (C.c_int, ["PP", C.c_int, C.POINTER(C.c_void_p)]),
+    "rtfhe_ctx_create_multi": (C.c_int, ["PP", C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rtfhe_ctx_device_count": (C.c_int, [C.c_void_p]),
     "rtfhe_ctx_destroy": (None, [C.c_void_p]),
+    "rtfhe_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "rtfhe_host_free": (None, [C.c_void_p]),
     "rtfhe_last_error": (C.c_char_p, [C.c_void_p]),
     "rtfhe_version": (C.c_char_p, []),
     "rtfhe_device_count": (C.c_int, []),
@@ -53,6 +57,10 @@ _SIGNATURES = {
     "rtfhe_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_gate_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rtfhe_circuit_wave_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "rtfhe_circuit_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
+                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rtfhe_circuit_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_circuit_destroy": (None, [C.c_void_p]),
     "rtfhe_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_timer_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -225,6 +225,7 @@ class CircuitRunner:
         self.wires[idx] = cz[0]
         self.wires[idx + 1] = cz[1]
         self.waves = []
+        self._circuit, self._flat = None, None
         off = (np.arange(replicas, dtype=np.int64) * W)[:, None]
         for wave in net.levels():
             ops = np.array([net.gates[g][0] for g in wave], np.int32)
@@ -242,12 +243,36 @@ class CircuitRunner:
         view = self.wires.view(self.R, W, self.n1)
         view[:, 2:2 + self.net.num_inputs] = torch.from_numpy(cts.view(np.int32)).cuda()
 
-    def run(self):
+    def run(self, graph=True):
+        """Evaluates the netlist.  graph=True (default): all dependency waves were recorded once into a HIP graph
+        (rtfhe_circuit_create) and are replayed as ONE submission; graph=False: one rtfhe_circuit_wave_dev call per wave.
+        Either way the call returns after the device has finished, and a gate the device skipped (wire index or opcode
+        out of range) raises RtfheError HERE, not at some later unrelated sync."""
         import torch
         st = torch.cuda.current_stream().cuda_stream
-        for ops, i0, i1, io, cnt in self.waves:
-            self.e.circuit_wave_dev(ops, i0, i1, io, self.wires, self.R * self.net.num_wires, cnt, st)
+        if graph and self.waves:
+            if self._circuit is None:
+                cat = lambda k: torch.cat([w[k] for w in self.waves]).contiguous()
+                self._flat = (cat(0), cat(1), cat(2), cat(3))
+                offs = np.concatenate([[0], np.cumsum([w[4] for w in self.waves])]).astype(np.int32)
+                self._circuit = self.e.circuit_create(*self._flat, offs, self.wires, self.R * self.net.num_wires)
+            self.e.circuit_launch(self._circuit, st)
+        else:
+            for ops, i0, i1, io, cnt in self.waves:
+                self.e.circuit_wave_dev(ops, i0, i1, io, self.wires, self.R * self.net.num_wires, cnt, st)
+        self.e.sync(st)
         return self
+
+    def close(self):
+        if getattr(self, "_circuit", None) is not None:
+            self.e.circuit_destroy(self._circuit)
+            self._circuit = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def outputs(self):
         """uint32[replicas][num_outputs][n+1]."""

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "rtfhe_kernels.hpp"
@@ -169,13 +171,22 @@ struct rtfhe_ctx {
     uint32_t* d_ksk = nullptr;
     int ksw = 0;
     bool has_bk = false, has_ksk = false;
-    void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr;   // staging for host-pointer calls
+    void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr;   // device staging for host-pointer calls
     size_t cap_a = 0, cap_b = 0, cap_c = 0;
+    void* h_pin[3] = {nullptr, nullptr, nullptr};                     // pinned host staging (pageable caller buffers go through it)
+    size_t cap_pin[3] = {0, 0, 0};
+    bool stage_pinned = true;                                         // RTFHE_STAGING=0: hand pageable pointers to hipMemcpyAsync as they are
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
     int32_t* d_fault = nullptr;            // set by a kernel that skipped a netlist gate (bad wire index / opcode)
     unsigned long long* d_dbg = nullptr;   // RTFHE_WG_STAMPS builds: 128 words of phase timings
+    std::unordered_map<const void*, size_t> lds_allowed;   // kernel -> dynamic LDS bytes already granted on this device
+    // multi-device context (rtfhe_ctx_create_multi): one full single-device context per further device; `this` is device 0 of
+    // the set.  Keys are loaded once on this context and copied device-to-device; host-pointer batches are sharded.
+    std::vector<rtfhe_ctx*> peers;
+    void* h_mux[2] = {nullptr, nullptr};   // device intermediates of rtfhe_mux_batch
+    size_t cap_mux = 0;
     int num_cus = 256;
     int force_waves = 0;   // RTFHE_FORCE_WAVES=1|4|8 (tuning knob: 1 = workgroup-per-gate kernel)
     int wg_max = 512;      // RTFHE_WG_MAX_GATES: largest batch routed to the workgroup-per-gate kernel
@@ -213,9 +224,15 @@ int ensure(rtfhe_ctx* ctx, void** ptr, size_t* cap, size_t bytes) {
     return 0;
 }
 
+// The dynamic-LDS limit of a kernel is a per-device attribute: granted once (normally at context creation, see
+// prime_kernel_attributes) and remembered, so that a launch costs no runtime call beyond the launch itself.
 template <typename K>
 int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
-    HIPCHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const void* key = reinterpret_cast<const void*>(kernel);
+    auto it = ctx->lds_allowed.find(key);
+    if (it != ctx->lds_allowed.end() && it->second >= bytes) return 0;
+    HIPCHECK(ctx, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_allowed[key] = bytes;
     return 0;
 }
 
@@ -468,6 +485,92 @@ int use(rtfhe_ctx* ctx) {
     return 0;
 }
 
+// grants every bootstrap kernel of this context's parameter set its dynamic LDS once, at context creation
+int prime_kernel_attributes(rtfhe_ctx* ctx) {
+    const int npad = (ctx->p.n + 1 + 63) / 64 * 64;
+    if (ctx->logn == 10) {
+        if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 4>, PairLds::bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_wg<10, 3, 6, 8, 2, KSQ>, WgLds<10, 3>::bytes(npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<10>(4, npad, bootstrap_dual_xbuf(10, 4)))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 8>, bootstrap_lds_bytes<10>(8, npad, bootstrap_dual_xbuf(10, 8)))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 4>, NttPairLds::bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_ntt<3, 6, 8, 2, KSQ, 4>, ntt_lds_bytes(4, npad))) return rc;
+    } else {
+        if (int rc = allow_lds(ctx, k_bootstrap<11, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<11>(4, npad, bootstrap_dual_xbuf(11, 4)))) return rc;
+    }
+    return 0;
+}
+
+// true when `p` is host memory the GPU can DMA from directly (hipHostMalloc / hipHostRegister, e.g. rtfhe_host_alloc)
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int ensure_pinned(rtfhe_ctx* ctx, int slot, size_t bytes) {
+    if (ctx->cap_pin[slot] >= bytes && ctx->h_pin[slot]) return 0;
+    if (ctx->h_pin[slot]) HIPCHECK(ctx, hipHostFree(ctx->h_pin[slot]));
+    ctx->h_pin[slot] = nullptr; ctx->cap_pin[slot] = 0;
+    HIPCHECK(ctx, hipHostMalloc(&ctx->h_pin[slot], bytes ? bytes : 16, hipHostMallocDefault));
+    ctx->cap_pin[slot] = bytes;
+    return 0;
+}
+
+// host -> device on ctx->stream.  Caller-pinned memory is DMA'd as it is; pageable memory goes through the context's own
+// pinned staging buffer `slot` (one memcpy on the host, then an asynchronous DMA that overlaps the next host copy).
+int copy_in(rtfhe_ctx* ctx, void* dst, const void* src, size_t bytes, int slot) {
+    if (ctx->stage_pinned && !is_pinned_host(src)) {
+        if (int rc = ensure_pinned(ctx, slot, bytes)) return rc;
+        std::memcpy(ctx->h_pin[slot], src, bytes);
+        src = ctx->h_pin[slot];
+    }
+    HIPCHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+// device -> host on ctx->stream, synchronous on return
+int copy_out(rtfhe_ctx* ctx, void* dst, const void* src, size_t bytes, int slot) {
+    if (ctx->stage_pinned && !is_pinned_host(dst)) {
+        if (int rc = ensure_pinned(ctx, slot, bytes)) return rc;
+        HIPCHECK(ctx, hipMemcpyAsync(ctx->h_pin[slot], src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(dst, ctx->h_pin[slot], bytes);
+        return 0;
+    }
+    HIPCHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// contiguous range of device d of n_dev (sizes differ by at most one)
+inline size_t shard_begin(size_t count, int d, int n_dev) { return count * (size_t)d / (size_t)n_dev; }
+
+// runs fn(context of device d, d) for every device of a multi-device context, one host thread per device; first error wins
+template <typename F>
+int for_each_device(rtfhe_ctx* ctx, F fn) {
+    const int n_dev = 1 + (int)ctx->peers.size();
+    std::vector<int> rcs(n_dev, 0);
+    std::vector<std::thread> th;
+    for (int d = 1; d < n_dev; d++) th.emplace_back([&, d]() { rcs[d] = fn(ctx->peers[d - 1], d); });
+    rcs[0] = fn(ctx, 0);
+    for (auto& t : th) t.join();
+    for (int d = 0; d < n_dev; d++)
+        if (rcs[d]) return d == 0 ? rcs[0] : fail(ctx, rcs[d], "device " + std::to_string(ctx->peers[d - 1]->device) + ": " + ctx->peers[d - 1]->err);
+    return 0;
+}
+
+// device 0's copy of a key -> every peer (device-to-device; xGMI between the GPUs of one node)
+int replicate(rtfhe_ctx* ctx, rtfhe_ctx* peer, const void* src, void** dst_of_peer, size_t bytes) {
+    if (!*dst_of_peer) {
+        HIPCHECK(ctx, hipSetDevice(peer->device));
+        HIPCHECK(ctx, hipMalloc(dst_of_peer, bytes));
+    }
+    HIPCHECK(ctx, hipMemcpyPeer(*dst_of_peer, peer->device, src, ctx->device, bytes));
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -486,7 +589,7 @@ int rtfhe_device_count(void) {
     return n;
 }
 
-int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
+static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
     if (!p || !out) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
     *out = nullptr;
     if (p->N != 1024 && p->N != 2048) return fail(nullptr, RTFHE_ERR_INVALID, "supported TRLWE degrees: N = 1024, 2048");
@@ -510,7 +613,9 @@ int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
         ctx->wg_max = 2 * ctx->num_cus;
         if (const char* e = std::getenv("RTFHE_FORCE_WAVES")) ctx->force_waves = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_WG_MAX_GATES")) ctx->wg_max = std::atoi(e);
+        if (const char* e = std::getenv("RTFHE_STAGING")) ctx->stage_pinned = std::atoi(e) != 0;
     }
+    if (!rc) rc = prime_kernel_attributes(ctx);
     if (!rc) rc = upload_twiddles(ctx);
     if (!rc && (hipMalloc((void**)&ctx->d_fault, 4) != hipSuccess || hipMemset(ctx->d_fault, 0, 4) != hipSuccess))
         rc = fail(ctx, RTFHE_ERR_HIP, "hipMalloc failed");
@@ -525,6 +630,41 @@ int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) {
     return 0;
 }
 
+int rtfhe_ctx_create(const rtfhe_params* p, int device_id, rtfhe_ctx** out) { return create_single(p, device_id, out); }
+
+// One context over several GPUs of the node: device_ids[0] is the primary.  Keys loaded into the context are
+// transformed once on the primary and copied device-to-device to the others; host-pointer batch calls (rtfhe_gate_batch,
+// rtfhe_mux_batch, rtfhe_bootstrap_batch) shard contiguous gate ranges over the devices, one host thread and one stream per
+// device, with direct host<->device copies per device.  *_dev and stage-level calls run on the primary device.
+int rtfhe_ctx_create_multi(const rtfhe_params* p, const int* device_ids, int n_dev, rtfhe_ctx** out) {
+    if (!p || !out || !device_ids) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n_dev < 1 || n_dev > 64) return fail(nullptr, RTFHE_ERR_INVALID, "n_dev out of range");
+    for (int a = 0; a < n_dev; a++)
+        for (int b = a + 1; b < n_dev; b++)
+            if (device_ids[a] == device_ids[b]) return fail(nullptr, RTFHE_ERR_INVALID, "device_ids must be distinct");
+    rtfhe_ctx* ctx = nullptr;
+    if (int rc = create_single(p, device_ids[0], &ctx)) return rc;
+    for (int d = 1; d < n_dev; d++) {
+        rtfhe_ctx* peer = nullptr;
+        if (int rc = create_single(p, device_ids[d], &peer)) { rtfhe_ctx_destroy(ctx); return rc; }
+        ctx->peers.push_back(peer);
+    }
+    (void)hipSetDevice(ctx->device);
+    *out = ctx;
+    return 0;
+}
+
+int rtfhe_ctx_device_count(const rtfhe_ctx* ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
+// pinned host memory for ciphertext buffers: host-pointer calls DMA straight from / into it (no staging copy)
+void* rtfhe_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void rtfhe_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 #ifdef RTFHE_WG_STAMPS
 extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out128) {
     if (!ctx || !ctx->d_dbg) return RTFHE_ERR_STATE;
@@ -534,6 +674,8 @@ extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out12
 
 void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (!ctx) return;
+    for (rtfhe_ctx* peer : ctx->peers) rtfhe_ctx_destroy(peer);
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
@@ -546,6 +688,8 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_b) (void)hipFree(ctx->d_b);
     if (ctx->d_c) (void)hipFree(ctx->d_c);
+    for (void* h : ctx->h_pin) if (h) (void)hipHostFree(h);
+    for (void* m : ctx->h_mux) if (m) (void)hipFree(m);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -557,6 +701,7 @@ int rtfhe_set_backend(rtfhe_ctx* ctx, int backend) {
     if (backend != RTFHE_BACKEND_FFT64_MIRROR && backend != RTFHE_BACKEND_NTT_EXACT) return fail(ctx, RTFHE_ERR_INVALID, "unknown backend");
     if (backend == RTFHE_BACKEND_NTT_EXACT && ctx->p.N != ntt::N) return fail(ctx, RTFHE_ERR_INVALID, "the NTT backend supports N = 1024");
     ctx->backend = backend;
+    for (rtfhe_ctx* peer : ctx->peers) peer->backend = backend;
     return 0;
 }
 
@@ -576,7 +721,12 @@ int rtfhe_set_twiddles(rtfhe_ctx* ctx, const double* ifft_table, const double* f
     if (int rc = upload_twiddles(ctx)) return rc;
     // a key loaded in torus form was transformed with the old tables: redo it (spectra loaded through rtfhe_load_bk_fft
     // are the caller's and stay as they are)
-    if (ctx->has_bk && ctx->d_bk_torus) return transform_bk_from_torus(ctx);
+    if (ctx->has_bk && ctx->d_bk_torus)
+        if (int rc = transform_bk_from_torus(ctx)) return rc;
+    for (rtfhe_ctx* peer : ctx->peers) {
+        if (int rc = rtfhe_set_twiddles(peer, ifft_table, fft_table)) return fail(ctx, rc, peer->err);
+        HIPCHECK(ctx, hipSetDevice(ctx->device));
+    }
     return 0;
 }
 
@@ -590,6 +740,11 @@ int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
     ctx->ntt_ready = false;
     if (int rc = transform_bk_from_torus(ctx)) return rc;
     ctx->has_bk = true;
+    for (rtfhe_ctx* peer : ctx->peers) {      // the transformed key and its torus form, device to device
+        if (int rc = replicate(ctx, peer, ctx->d_bk, (void**)&peer->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx))) return rc;
+        if (int rc = replicate(ctx, peer, ctx->d_bk_torus, (void**)&peer->d_bk_torus, words * 4)) return rc;
+        peer->ntt_ready = false; peer->has_bk = true;
+    }
     return 0;
 }
 
@@ -608,6 +763,11 @@ int rtfhe_load_bk_fft(rtfhe_ctx* ctx, const double* bk_f) {
     if (ctx->d_bk_torus) { (void)hipFree(ctx->d_bk_torus); ctx->d_bk_torus = nullptr; }   // no torus form of this key
     ctx->ntt_ready = false;
     ctx->has_bk = true;
+    for (rtfhe_ctx* peer : ctx->peers) {
+        if (int rc = replicate(ctx, peer, ctx->d_bk, (void**)&peer->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx))) return rc;
+        if (peer->d_bk_torus) { (void)hipSetDevice(peer->device); (void)hipFree(peer->d_bk_torus); peer->d_bk_torus = nullptr; (void)hipSetDevice(ctx->device); }
+        peer->ntt_ready = false; peer->has_bk = true;
+    }
     return 0;
 }
 
@@ -643,6 +803,10 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
     HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_ksk = true;
+    for (rtfhe_ctx* peer : ctx->peers) {
+        if (int rc = replicate(ctx, peer, ctx->d_ksk, (void**)&peer->d_ksk, (dev_rows + 1) * ksw * 4)) return rc;
+        peer->has_ksk = true;
+    }
     return 0;
 }
 
@@ -661,6 +825,69 @@ int rtfhe_circuit_wave_dev(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0
     return launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, count, (hipStream_t)stream,
                             (const int32_t*)d_ops, (const int32_t*)d_idx0, (const int32_t*)d_idx1, (const int32_t*)d_idx_out,
                             (int32_t)num_wires);
+}
+
+// ---- a whole levelised netlist as ONE submission: its dependency waves captured once into a HIP graph, replayed per run ----
+struct rtfhe_circuit {
+    rtfhe_ctx* ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int32_t waves = 0;
+    int64_t launches = 0;      // kernel launches one replay stands for
+};
+
+int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, const void* d_idx1, const void* d_idx_out,
+                         const int32_t* wave_offsets, int32_t num_waves, void* d_wires, size_t num_wires, rtfhe_circuit** out) {
+    if (int rc = use(ctx)) return rc;
+    if (!out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (!d_ops || !d_idx0 || !d_idx1 || !d_idx_out || !d_wires || !wave_offsets) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (num_waves < 1 || num_wires == 0 || num_wires > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "num_waves / num_wires out of range");
+    for (int32_t w = 0; w < num_waves; w++)
+        if (wave_offsets[w] < 0 || wave_offsets[w + 1] <= wave_offsets[w]) return fail(ctx, RTFHE_ERR_INVALID, "wave_offsets must be strictly increasing from >= 0");
+    if (!ctx->has_bk || !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "keys not loaded");
+    if (ctx->backend == RTFHE_BACKEND_NTT_EXACT)
+        if (int rc = ntt_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
+    rtfhe_circuit* c = new (std::nothrow) rtfhe_circuit();
+    if (!c) return fail(ctx, RTFHE_ERR_NOMEM, "out of host memory");
+    c->ctx = ctx; c->waves = num_waves;
+    const int64_t before = ctx->launches;
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    int rc = 0;
+    for (int32_t w = 0; w < num_waves && !rc; w++) {
+        const size_t off = (size_t)wave_offsets[w], cnt = (size_t)(wave_offsets[w + 1] - wave_offsets[w]);
+        rc = launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, cnt, ctx->stream,
+                              (const int32_t*)d_ops + off, (const int32_t*)d_idx0 + off, (const int32_t*)d_idx1 + off,
+                              (const int32_t*)d_idx_out + off, (int32_t)num_wires);
+    }
+    e = hipStreamEndCapture(ctx->stream, &c->graph);
+    c->launches = ctx->launches - before;
+    ctx->launches = before;
+    if (rc) { if (c->graph) (void)hipGraphDestroy(c->graph); delete c; return rc; }
+    if (e != hipSuccess) { delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(c->graph); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    *out = c;
+    return 0;
+}
+
+int rtfhe_circuit_launch(rtfhe_circuit* c, void* stream) {
+    if (!c || !c->ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null circuit");
+    rtfhe_ctx* ctx = c->ctx;
+    if (int rc = use(ctx)) return rc;
+    HIPCHECK(ctx, hipGraphLaunch(c->exec, (hipStream_t)stream));
+    ctx->launches += c->launches;
+    return 0;
+}
+
+void rtfhe_circuit_destroy(rtfhe_circuit* c) {
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->exec) (void)hipGraphExecDestroy(c->exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    delete c;
 }
 
 int rtfhe_sync(rtfhe_ctx* ctx, void* stream) {
@@ -694,25 +921,36 @@ int rtfhe_timer_end(rtfhe_ctx* ctx, void* stream, double* ms, int64_t* launches)
     return 0;
 }
 
-static int run_host_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const uint32_t* in0, const uint32_t* in1,
-                              uint32_t* out, size_t count, size_t out_words) {
+static int run_host_bootstrap_one(rtfhe_ctx* ctx, int op, int mode, int steps, const uint32_t* in0, const uint32_t* in1,
+                                  uint32_t* out, size_t count, size_t out_words) {
     if (int rc = use(ctx)) return rc;
-    if (!in0 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (count == 0) return 0;
     const size_t in_bytes = count * ((size_t)ctx->p.n + 1) * 4, out_bytes = count * out_words * 4;
     if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;
     if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, out_bytes)) return rc;
-    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, in0, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = copy_in(ctx, ctx->d_a, in0, in_bytes, 0)) return rc;
     const void* d1 = nullptr;
     if (in1) {
         if (int rc = ensure(ctx, &ctx->d_b, &ctx->cap_b, in_bytes)) return rc;
-        HIPCHECK(ctx, hipMemcpyAsync(ctx->d_b, in1, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = copy_in(ctx, ctx->d_b, in1, in_bytes, 1)) return rc;
         d1 = ctx->d_b;
     }
     if (int rc = launch_bootstrap(ctx, op, mode, steps, ctx->d_a, d1, ctx->d_c, count, ctx->stream)) return rc;
-    HIPCHECK(ctx, hipMemcpyAsync(out, ctx->d_c, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return copy_out(ctx, out, ctx->d_c, out_bytes, 2);
+}
+
+// host-pointer batch: on a multi-device context device d bootstraps the contiguous range [count d / D, count (d+1) / D)
+static int run_host_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const uint32_t* in0, const uint32_t* in1,
+                              uint32_t* out, size_t count, size_t out_words) {
+    if (int rc = use(ctx)) return rc;
+    if (!in0 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (ctx->peers.empty()) return run_host_bootstrap_one(ctx, op, mode, steps, in0, in1, out, count, out_words);
+    const int n_dev = 1 + (int)ctx->peers.size();
+    const size_t w = (size_t)ctx->p.n + 1;
+    return for_each_device(ctx, [&](rtfhe_ctx* c, int d) {
+        const size_t b = shard_begin(count, d, n_dev), e = shard_begin(count, d + 1, n_dev);
+        return run_host_bootstrap_one(c, op, mode, steps, in0 + b * w, in1 ? in1 + b * w : nullptr, out + b * out_words, e - b, out_words);
+    });
 }
 
 int rtfhe_gate_batch(rtfhe_ctx* ctx, int op, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
@@ -733,15 +971,44 @@ int rtfhe_blind_rotate_batch(rtfhe_ctx* ctx, const uint32_t* tlwe, int32_t steps
     return run_host_bootstrap(ctx, RTFHE_COPY, MODE_BLIND_ROTATE, steps, tlwe, nullptr, acc, count, (size_t)2 * ctx->p.N);
 }
 
-// hom_mux (tfhe.rs:27-40): i1 = AND(c, in1); i0 = AND(-c, in0); bootstrap(i1 + i0 + 1/8) -- the last line is hom_or(i1, i0)
+// hom_mux (tfhe.rs:27-40): i1 = AND(c, in1); i0 = AND(-c, in0); bootstrap(i1 + i0 + 1/8) -- the last line is hom_or(i1, i0).
+// One copy in (c, in0, in1), three launches back to back on the context's stream with i1 / i0 kept on the device, one copy out.
+static int mux_one(rtfhe_ctx* ctx, const uint32_t* c, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
+    if (int rc = use(ctx)) return rc;
+    if (count == 0) return 0;
+    const size_t bytes = count * ((size_t)ctx->p.n + 1) * 4;
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_b, &ctx->cap_b, bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, bytes)) return rc;
+    if (ctx->cap_mux < bytes) {
+        for (void*& m : ctx->h_mux) { if (m) HIPCHECK(ctx, hipFree(m)); m = nullptr; }
+        ctx->cap_mux = 0;
+        for (void*& m : ctx->h_mux) HIPCHECK(ctx, hipMalloc(&m, bytes));
+        ctx->cap_mux = bytes;
+    }
+    if (int rc = copy_in(ctx, ctx->d_a, c, bytes, 0)) return rc;
+    if (int rc = copy_in(ctx, ctx->d_b, in1, bytes, 1)) return rc;
+    if (int rc = copy_in(ctx, ctx->d_c, in0, bytes, 2)) return rc;
+    const int n = ctx->p.n;
+    if (int rc = launch_bootstrap(ctx, RTFHE_AND, MODE_GATE, n, ctx->d_a, ctx->d_b, ctx->h_mux[0], count, ctx->stream)) return rc;     // i1
+    if (int rc = launch_bootstrap(ctx, RTFHE_ANDNY, MODE_GATE, n, ctx->d_a, ctx->d_c, ctx->h_mux[1], count, ctx->stream)) return rc;   // i0
+    if (int rc = launch_bootstrap(ctx, RTFHE_OR, MODE_GATE, n, ctx->h_mux[0], ctx->h_mux[1], ctx->d_a, count, ctx->stream)) return rc;
+    return copy_out(ctx, out, ctx->d_a, bytes, 0);
+}
+
 int rtfhe_mux_batch(rtfhe_ctx* ctx, const uint32_t* c, const uint32_t* in0, const uint32_t* in1, uint32_t* out, size_t count) {
-    if (!ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null context");
+    if (int rc = use(ctx)) return rc;
     if (!c || !in0 || !in1 || !out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
-    const size_t total = count * ((size_t)ctx->p.n + 1);
-    std::vector<uint32_t> i1(total), i0(total);
-    if (int rc = rtfhe_gate_batch(ctx, RTFHE_AND, c, in1, i1.data(), count)) return rc;
-    if (int rc = rtfhe_gate_batch(ctx, RTFHE_ANDNY, c, in0, i0.data(), count)) return rc;
-    return rtfhe_gate_batch(ctx, RTFHE_OR, i1.data(), i0.data(), out, count);
+    if (!ctx->has_bk) return fail(ctx, RTFHE_ERR_STATE, "bootstrapping key not loaded");
+    if (!ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "key-switching key not loaded");
+    if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
+    if (ctx->peers.empty()) return mux_one(ctx, c, in0, in1, out, count);
+    const int n_dev = 1 + (int)ctx->peers.size();
+    const size_t w = (size_t)ctx->p.n + 1;
+    return for_each_device(ctx, [&](rtfhe_ctx* cx, int d) {
+        const size_t b = shard_begin(count, d, n_dev), e = shard_begin(count, d + 1, n_dev);
+        return mux_one(cx, c + b * w, in0 + b * w, in1 + b * w, out + b * w, e - b);
+    });
 }
 
 int rtfhe_external_product_batch(rtfhe_ctx* ctx, const int32_t* bk_index, const uint32_t* trlwe, uint32_t* out, size_t count) {

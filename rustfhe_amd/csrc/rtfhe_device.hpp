@@ -400,6 +400,19 @@ __device__ __forceinline__ uint32_t trunc_to_torus(double x) {
     return (uint32_t)__double_as_longlong(y);
 }
 
+// The same conversion over the reference's whole range: Torus32(int64_t(x)) is defined for every |x| < 2^63 (cvttsd2si), the
+// magic-add form above only below 2^51.  The stage-level entry point rtfhe_fft_u32_batch takes arbitrary spectra and uses
+// this one: t = trunc(x) splits exactly into hi * 2^32 + lo (power-of-two scaling, floor and the fused multiply-add below
+// are all exact for an integer-valued double), lo in [0, 2^32) is t mod 2^32.  Out of range / NaN gives 0, the low word of
+// the 0x8000000000000000 the x86 conversion returns.
+__device__ __forceinline__ uint32_t trunc_to_torus_wide(double x) {
+    const double t = __builtin_trunc(x);
+    if (!(__builtin_fabs(t) < 9223372036854775808.0)) return 0u;
+    const double hi = __builtin_floor(t * 2.3283064365386963e-10);       // 2^-32
+    const double lo = __builtin_fma(hi, -4294967296.0, t);
+    return (uint32_t)lo;
+}
+
 // make_decomp_mask(l, bits), utils/src/math.rs:542-560
 __host__ __device__ constexpr uint32_t decomp_mask(int l, int bits) {
     uint32_t u = 0;

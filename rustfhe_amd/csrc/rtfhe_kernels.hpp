@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_inverse(const FftArgs a) 
         fft_inverse<LOGN>(re, im, tw, tw, xbuf, lane);
         uint32_t* dst = reinterpret_cast<uint32_t*>(a.dst) + (size_t)g * N;
 #pragma unroll
-        for (int m = 0; m < R; m++) { dst[lane + 64 * m] = trunc_to_torus(re[m]); dst[lane + 64 * m + P] = trunc_to_torus(im[m]); }
+        for (int m = 0; m < R; m++) { dst[lane + 64 * m] = trunc_to_torus_wide(re[m]); dst[lane + 64 * m + P] = trunc_to_torus_wide(im[m]); }
     }
 }
 

@@ -27,15 +27,26 @@ def _ptr(a):
 
 
 class Engine:
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, devices=None):
+        """device: one GPU (rtfhe_ctx_create).  devices=[d0, d1, ...]: one context over several GPUs of the node
+        (rtfhe_ctx_create_multi): keys are loaded once and replicated device-to-device, the host-buffer batch calls shard
+        contiguous gate ranges over them; *_dev and stage-level calls stay on devices[0]."""
         self.L = _ffi.load()
         self.p = params or Params()
         h = C.c_void_p()
-        rc = self.L.rtfhe_ctx_create(C.byref(self.p), device, C.byref(h))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            rc = self.L.rtfhe_ctx_create_multi(C.byref(self.p), ids, len(devices), C.byref(h))
+            device = devices[0] if len(devices) else 0
+        else:
+            rc = self.L.rtfhe_ctx_create(C.byref(self.p), device, C.byref(h))
         if rc != 0:
             raise RtfheError(rc, (self.L.rtfhe_last_error(None) or b"").decode())
         self.h = h
         self.device = device
+
+    def device_count(self):
+        return self.L.rtfhe_ctx_device_count(self.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -134,6 +145,22 @@ class Engine:
                                                self._dev(d_idx_out), self._dev(d_wires), num_wires, count,
                                                C.c_void_p(stream) if stream else None))
 
+    def circuit_create(self, d_ops, d_idx0, d_idx1, d_idx_out, wave_offsets, d_wires, num_wires):
+        """Records the waves [wave_offsets[w], wave_offsets[w+1]) of a levelised netlist into one HIP graph; returns a handle
+        for circuit_launch / circuit_destroy.  The device arrays must stay alive while the handle exists."""
+        offs = _np(wave_offsets, np.int32)
+        h = C.c_void_p()
+        self._ck(self.L.rtfhe_circuit_create(self.h, self._dev(d_ops), self._dev(d_idx0), self._dev(d_idx1), self._dev(d_idx_out),
+                                             offs.ctypes.data_as(C.POINTER(C.c_int32)), offs.size - 1, self._dev(d_wires), num_wires,
+                                             C.byref(h)))
+        return h
+
+    def circuit_launch(self, circuit, stream=None):
+        self._ck(self.L.rtfhe_circuit_launch(circuit, C.c_void_p(stream) if stream else None))
+
+    def circuit_destroy(self, circuit):
+        self.L.rtfhe_circuit_destroy(circuit)
+
     def sync(self, stream=None):
         self._ck(self.L.rtfhe_sync(self.h, C.c_void_p(stream) if stream else None))
 
@@ -178,6 +205,24 @@ class Engine:
         res = np.empty(src.shape, np.uint32)
         self._ck(self.L.rtfhe_fft_u32_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
         return res
+
+
+def pinned_empty(shape, dtype=np.uint32):
+    """numpy array over pinned host memory (rtfhe_host_alloc): host-pointer calls DMA straight from / into it.  The memory
+    is released when the array (and every view of it) is garbage-collected."""
+    L = _ffi.load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = L.rtfhe_host_alloc(n)
+    if not ptr:
+        raise RtfheError(_ffi.ERR_NOMEM, "rtfhe_host_alloc failed (needs a HIP device)")
+
+    class _Owner:
+        def __del__(self, _free=L.rtfhe_host_free, _p=ptr):
+            _free(C.c_void_p(_p))
+    buf = (C.c_char * n).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    buf._owner = _Owner()
+    return arr
 
 
 # ---- host-side key generation / encryption (C ABI, no GPU needed) --------------------------------

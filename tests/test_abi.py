@@ -37,7 +37,14 @@ int main(void) {
     if (p.n != 635 || p.N != 1024 || p.l != 3 || p.bgbit != 6 || p.ks_t != 8 || p.ks_basebit != 2) return 2;
     int rc = rtfhe_ctx_create(&p, 0, &ctx);
     printf("%d %d %s\\n", rc, rtfhe_device_count(), rtfhe_version());
-    if (rc == 0) rtfhe_ctx_destroy(ctx);
+    if (rc == 0) { if (rtfhe_ctx_device_count(ctx) != 1) return 3; rtfhe_ctx_destroy(ctx); }
+    /* the multi-device form: same refusal without a GPU, argument checks first */
+    int ids[2] = {0, 0}; rtfhe_ctx *m = 0;
+    if (rtfhe_ctx_create_multi(&p, ids, 2, &m) != RTFHE_ERR_INVALID || m) return 4;      /* duplicate device */
+    if (rtfhe_ctx_create_multi(&p, ids, 0, &m) != RTFHE_ERR_INVALID) return 5;
+    int rcm = rtfhe_ctx_create_multi(&p, ids, 1, &m);
+    if (rtfhe_device_count() == 0 ? (rcm != RTFHE_ERR_NO_DEVICE || m) : (rcm != 0 || rtfhe_ctx_device_count(m) != 1)) return 6;
+    if (m) rtfhe_ctx_destroy(m);
     return 0;
 }
 ''')

@@ -132,3 +132,50 @@ def test_netlist_wave_rejects_bad_wire_indices(engine, keys):
     engine.circuit_wave_dev(dev([R.AND]), dev([0]), dev([2]), dev([6]), wires, W, 1, st)
     engine.sync(st)
     assert keys.decrypt_bits(wires[6:7].cpu().numpy().view(np.uint32)) == [1]
+
+
+@pytest.mark.gpu
+def test_circuit_graph_replay_equals_wave_by_wave(engine, params, keys):
+    """The netlist recorded once into a HIP graph (rtfhe_circuit_create) and replayed as one submission gives the words
+    the wave-by-wave launches give, and can be replayed on new inputs."""
+    from rustfhe_amd.circuit import CircuitRunner, ripple_carry_adder
+    net = ripple_carry_adder(4, nand_only=True)
+    reps = 3
+    rng = np.random.default_rng(5)
+    for trial in range(2):
+        bits = rng.integers(0, 2, (reps, 8))
+        cts = keys.encrypt_bits(bits.reshape(-1)).reshape(reps, 8, params.n + 1)
+        if trial == 0:
+            g, w = CircuitRunner(engine, net, reps), CircuitRunner(engine, net, reps)
+        g.set_inputs(cts)
+        w.set_inputs(cts)
+        a = g.run(graph=True).outputs()
+        b = w.run(graph=False).outputs()
+        assert np.array_equal(a, b)
+        dec = np.array(keys.decrypt_bits(a.reshape(-1, params.n + 1))).reshape(reps, 5)
+        A = (bits[:, :4] * (1 << np.arange(4))).sum(axis=1)
+        B = (bits[:, 4:] * (1 << np.arange(4))).sum(axis=1)
+        assert np.array_equal((dec * (1 << np.arange(5))).sum(axis=1), A + B)
+    g.close()
+    w.close()
+
+
+@pytest.mark.gpu
+def test_circuit_runner_reports_a_skipped_gate_at_run(engine, keys):
+    """A netlist with a wire index out of range is caught on the device; CircuitRunner.run() surfaces it itself (it used to
+    leave the sticky fault for some later, unrelated sync)."""
+    import rustfhe_amd as R
+    from rustfhe_amd.circuit import CircuitRunner, Netlist
+    for graph in (False, True):
+        net = Netlist()
+        a, b = net.inputs(2)
+        net.output(net.nand(a, b))
+        run = CircuitRunner(engine, net, 1)
+        run.set_inputs(keys.encrypt_bits([1, 1])[None])
+        ops, i0, i1, io, cnt = run.waves[0]
+        i0[0] = 1 << 20                                   # corrupt the recorded wave: far outside the wire table
+        with pytest.raises(R.RtfheError) as ei:
+            run.run(graph=graph)
+        assert ei.value.code == R._ffi.ERR_INVALID
+        run.close()
+    engine.sync()                                         # reported once: the context is clean again

@@ -163,3 +163,67 @@ def test_dispatch_boundaries_are_seamless(engine, params, keys):
     # a long run of launches leaves results unchanged (no state carried between calls)
     for _ in range(20):
         assert np.array_equal(engine.gate_batch(R.NAND, c0[:300], c1[:300]), full[:300])
+
+
+def test_multi_device_context_with_one_device_equals_single(params, keys, gold_gate):
+    """rtfhe_ctx_create_multi (the entry a Rust hom_nand_batch binds for a whole node): with n_dev = 1 every host-pointer
+    batch call gives the words rtfhe_gate_batch gives; the golden gate and the MUX come out bit for bit."""
+    import rustfhe_amd as R
+    p = R.Params(n=params.n, N=params.N, l=params.l, bgbit=params.bgbit, ks_t=params.ks_t, ks_basebit=params.ks_basebit)
+    m = R.Engine(p, devices=[0])
+    assert m.device_count() == 1
+    m.load_bk_torus(keys.bk_t)
+    m.load_ksk(keys.ksk)
+    ops, in0, in1 = gold_gate["ops"], gold_gate["in0"], gold_gate["in1"]
+    for g in range(len(ops)):
+        assert np.array_equal(m.gate_batch(int(ops[g]), in0[g:g + 1], in1[g:g + 1])[0], gold_gate["out"][g])
+    assert np.array_equal(m.mux_batch(in0[2:3], in0[0:1], in1[1:2])[0], gold_gate["mux_out"])
+    rng = np.random.default_rng(17)
+    b0, b1 = rng.integers(0, 2, 300), rng.integers(0, 2, 300)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    s = R.Engine(p, 0)
+    s.load_bk_torus(keys.bk_t)
+    s.load_ksk(keys.ksk)
+    assert np.array_equal(m.gate_batch(R.NAND, c0, c1), s.gate_batch(R.NAND, c0, c1))
+    with pytest.raises(R.RtfheError):
+        R.Engine(p, devices=[0, 0])
+    with pytest.raises(R.RtfheError):
+        R.Engine(p, devices=[0, 4096])
+    m.close()
+    s.close()
+
+
+def test_pinned_and_pageable_host_buffers_agree(engine, params, keys):
+    """Host-pointer calls DMA straight from rtfhe_host_alloc memory and stage any other pointer through the context's
+    pinned buffers: same words either way."""
+    import rustfhe_amd as R
+    rng = np.random.default_rng(23)
+    b0, b1 = rng.integers(0, 2, 200), rng.integers(0, 2, 200)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    p0, p1 = R.pinned_empty(c0.shape), R.pinned_empty(c1.shape)
+    p0[:], p1[:] = c0, c1
+    a = engine.gate_batch(R.XOR, c0, c1)
+    b = engine.gate_batch(R.XOR, p0, p1)
+    assert np.array_equal(a, b) and keys.decrypt_bits(a) == list(b0 ^ b1)
+    del p0, p1
+
+
+def test_key_file_feeds_an_engine(tmp_path, params, keys, gold_gate):
+    """The wire format on the path it exists for: a key file written by rtfhe_keys_write is read back, loaded into a
+    fresh context and produces the golden gate outputs."""
+    import rustfhe_amd as R
+    p = R.Params(n=params.n, N=params.N, l=params.l, bgbit=params.bgbit, ks_t=params.ks_t, ks_basebit=params.ks_basebit)
+    path = str(tmp_path / "server.rtfhe")
+    R.save_keys(path, p, None, None, keys.bk_t, keys.ksk)            # public part only: what a server holds
+    q, k0, k1, bk, ksk = R.load_keys(path)
+    assert k0 is None and k1 is None and (q.n, q.N) == (p.n, p.N)
+    e = R.Engine(q, 0)
+    e.load_bk_torus(bk)
+    e.load_ksk(ksk)
+    g = 0
+    out = e.gate_batch(int(gold_gate["ops"][g]), gold_gate["in0"][g:g + 1], gold_gate["in1"][g:g + 1])
+    assert np.array_equal(out[0], gold_gate["out"][g])
+    cts = str(tmp_path / "batch.rtfhe")
+    R.save_tlwe(cts, q, out)
+    assert np.array_equal(R.load_tlwe(cts), out)
+    e.close()

@@ -255,3 +255,21 @@ def test_twiddle_import_retransforms_a_torus_form_key(params, keys, gold_gate):
         assert np.array_equal(e.gate_batch(R.NAND, in0, in1), want)
     finally:
         e.close()
+
+
+def test_inverse_transform_beyond_2_pow_51(engine, orc, params):
+    """rtfhe_fft_u32_batch replaces Spqlios_fft_u32, whose Torus32(int64_t(x)) is defined up to 2^63
+    (fft_processor_spqlios.cpp:182); the gate path stays below 2^50 but this entry point takes arbitrary spectra."""
+    rng = np.random.default_rng(77)
+    pl = orc.Plan(params.N)
+    rows = []
+    for e in (40, 50, 52, 55, 58, 60):
+        rows.append(rng.standard_normal(params.N) * float(2 ** e))
+    spec = np.stack(rows)
+    spec[1, :4] = [2.0 ** 61, -(2.0 ** 61), 2.0 ** 53 + 2.0, -(2.0 ** 52) - 1.0]
+    res = engine.fft_u32_batch(spec)
+    exp = np.stack([pl.fft_u32(s) for s in spec])
+    vals = np.stack([pl.fft_f64(s) for s in spec]) if hasattr(pl, "fft_f64") else None
+    if vals is not None:
+        assert np.abs(vals).max() < 2.0 ** 63 and np.abs(vals).max() > 2.0 ** 52      # in the reference's range, past the old one
+    assert np.array_equal(res, exp)
