@@ -175,7 +175,8 @@ struct rtfhe_ctx {
     size_t cap_a = 0, cap_b = 0, cap_c = 0;
     void* h_pin[3] = {nullptr, nullptr, nullptr};                     // pinned host staging (pageable caller buffers go through it)
     size_t cap_pin[3] = {0, 0, 0};
-    bool stage_pinned = true;                                         // RTFHE_STAGING=0: hand pageable pointers to hipMemcpyAsync as they are
+    bool stage_pinned = false;                                        // RTFHE_STAGING=1: stage pageable caller buffers through h_pin (measured slower
+                                                                      // than the runtime's own pageable path: +3.4 % vs +1.5 % at 1024 gates)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
@@ -501,6 +502,14 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
     return 0;
 }
 
+// A *_dev entry point must never launch on a pointer the GPU cannot dereference (a host pointer passed by mistake would fault
+// the device): device, managed and pinned-host allocations pass, anything else is refused before the launch.
+bool gpu_accessible(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeHost;
+}
+
 // true when `p` is host memory the GPU can DMA from directly (hipHostMalloc / hipHostRegister, e.g. rtfhe_host_alloc)
 bool is_pinned_host(const void* p) {
     hipPointerAttribute_t a;
@@ -517,8 +526,8 @@ int ensure_pinned(rtfhe_ctx* ctx, int slot, size_t bytes) {
     return 0;
 }
 
-// host -> device on ctx->stream.  Caller-pinned memory is DMA'd as it is; pageable memory goes through the context's own
-// pinned staging buffer `slot` (one memcpy on the host, then an asynchronous DMA that overlaps the next host copy).
+// host -> device on ctx->stream.  Caller-pinned memory (rtfhe_host_alloc) is DMA'd as it is; pageable memory is handed to the
+// runtime's pageable path, or -- RTFHE_STAGING=1 -- goes through the context's own pinned staging buffer `slot`.
 int copy_in(rtfhe_ctx* ctx, void* dst, const void* src, size_t bytes, int slot) {
     if (ctx->stage_pinned && !is_pinned_host(src)) {
         if (int rc = ensure_pinned(ctx, slot, bytes)) return rc;
@@ -814,6 +823,8 @@ int rtfhe_gate_batch_dev(rtfhe_ctx* ctx, int op, const void* d_in0, const void* 
     if (int rc = use(ctx)) return rc;
     if (op < RTFHE_NAND || op > RTFHE_ANDNY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
     if (!d_in0 || !d_out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (!gpu_accessible(d_in0) || (d_in1 && !gpu_accessible(d_in1)) || !gpu_accessible(d_out))
+        return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_gate_batch_dev needs device pointers (got memory the GPU cannot address)");
     return launch_bootstrap(ctx, op, MODE_GATE, ctx->p.n, d_in0, d_in1, d_out, count, (hipStream_t)stream);
 }
 
@@ -822,6 +833,8 @@ int rtfhe_circuit_wave_dev(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0
     if (int rc = use(ctx)) return rc;
     if (!d_ops || !d_idx0 || !d_idx1 || !d_idx_out || !d_wires) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (num_wires == 0 || num_wires > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "num_wires out of range");
+    if (!gpu_accessible(d_ops) || !gpu_accessible(d_idx0) || !gpu_accessible(d_idx1) || !gpu_accessible(d_idx_out) || !gpu_accessible(d_wires))
+        return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_wave_dev needs device pointers (got memory the GPU cannot address)");
     return launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, count, (hipStream_t)stream,
                             (const int32_t*)d_ops, (const int32_t*)d_idx0, (const int32_t*)d_idx1, (const int32_t*)d_idx_out,
                             (int32_t)num_wires);
@@ -846,6 +859,8 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
     for (int32_t w = 0; w < num_waves; w++)
         if (wave_offsets[w] < 0 || wave_offsets[w + 1] <= wave_offsets[w]) return fail(ctx, RTFHE_ERR_INVALID, "wave_offsets must be strictly increasing from >= 0");
     if (!ctx->has_bk || !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "keys not loaded");
+    if (!gpu_accessible(d_ops) || !gpu_accessible(d_idx0) || !gpu_accessible(d_idx1) || !gpu_accessible(d_idx_out) || !gpu_accessible(d_wires))
+        return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_create needs device pointers (got memory the GPU cannot address)");
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT)
         if (int rc = ntt_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
     rtfhe_circuit* c = new (std::nothrow) rtfhe_circuit();

@@ -211,6 +211,9 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
                                          double* __restrict__ xbuf, int lane, double* __restrict__ ximbuf = nullptr) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
+#ifdef ABL_NOXCHG   // timing ablation only (wrong results): no LDS exchange at all
+    return;
+#endif
     auto slot = [&](int layout, int m) {
         // the pad map is the one of the exchange (f1 for L1<->L2, f2 for L2<->L3), the position the one of the layout
         const int pos = layout == 1 ? G::pos1(lane, m) : layout == 2 ? G::pos2(lane, m) : G::pos3(lane, m);
@@ -218,17 +221,21 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
     };
     if constexpr (DUAL) {
         double* xim = ximbuf ? ximbuf : xbuf + G::XSLOTS;   // second buffer: caller's, or right behind the first
+#ifndef ABL_NOXW
 #pragma unroll
         for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
 #pragma unroll
         for (int m = 0; m < R; m++) xim[slot(FROM, m)] = im[m];
+#endif
         wave_lds_sync();
+#ifndef ABL_NOXR
         // first stage of the next pass pairs m with m + R/2
 #pragma unroll
         for (int m = 0; m < R / 2; m++) {
             re[m] = xbuf[slot(TO, m)]; re[m + R / 2] = xbuf[slot(TO, m + R / 2)];
             im[m] = xim[slot(TO, m)];  im[m + R / 2] = xim[slot(TO, m + R / 2)];
         }
+#endif
         wave_lds_sync();
     } else {
 #pragma unroll
@@ -313,6 +320,58 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
                                             double* __restrict__ xim = nullptr) {
     fft_forward_a<LOGN, DUAL>(re, im, tw, xbuf, lane, xim);
     fft_forward_b<LOGN, DUAL>(re, im, tw, xbuf, lane, xim);
+}
+
+// NR forward transforms side by side in one wave (the digit rows of one polynomial): every pass loads its twiddles ONCE for
+// all rows (a third of the LDS twiddle reads), and row j's exchange is in flight while rows j+1.. compute -- DS instructions
+// of a wave execute in order, so the rows may share the exchange buffers back to back without waiting for each other's reads.
+// Same butterflies, same operands, same order per row as fft_forward.
+// part A: twist, pass 1, first exchange, pass 2, second exchange (issued).  part B: pass 3.  in: layout L1, out: layout L3.
+template <int LOGN, int NR>
+__device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
+                                                    const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
+    typedef Geo<LOGN> G;
+    constexpr int R = G::R;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {        // twist twiddles in two halves: R/2 of them live at a time
+        cplx wt[R / 2];
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) wt[m] = tw[G::TW_TWIST + lane + 64 * (half * (R / 2) + m)];
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+#pragma unroll
+            for (int m = 0; m < R / 2; m++) {
+                const int k = half * (R / 2) + m;
+                const double rc = re[j][k] * wt[m].x, ic = im[j][k] * wt[m].x, rs = re[j][k] * wt[m].y, is = im[j][k] * wt[m].y;
+                re[j][k] = rc - is;
+                im[j][k] = ic + rs;
+            }
+    }
+    {
+        Tw<R - 1> w1;
+        w1.load(tw + G::TW_P1 + lane, 64);
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            P12<R, G::LR - 1>::fwd(re[j], im[j], w1.w);
+            exchange<LOGN, 1, 2, true>(re[j], im[j], xbuf, lane, xim);
+        }
+    }
+    Tw<R - 1> w2;
+    w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        P12<R, G::LR - 1>::fwd(re[j], im[j], w2.w);
+        exchange<LOGN, 2, 3, true>(re[j], im[j], xbuf, lane, xim);
+    }
+}
+template <int LOGN, int NR>
+__device__ __forceinline__ void fft_forward_multi_b(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
+                                                    const cplx* __restrict__ tw) {
+    typedef Geo<LOGN> G;
+    Tw<G::NLOW - 4> w3;
+    w3.load(tw + G::TW_P3, 1);
+#pragma unroll
+    for (int j = 0; j < NR; j++) P3<G::R, G::NLOW, G::LOW - 1>::fwd(re[j], im[j], w3.w);
 }
 
 // The forward transform cut at its first exchange, for two waves: head = twist, pass 1, write half of the exchange (into

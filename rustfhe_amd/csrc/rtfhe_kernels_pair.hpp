@@ -39,7 +39,7 @@
 #define PAIR_LOWER_AT 2
 #endif
 #ifndef PAIR_RAISE_AT
-#define PAIR_RAISE_AT 9
+#define PAIR_RAISE_AT 8
 #endif
 
 namespace rtfhe {
@@ -47,7 +47,11 @@ namespace rtfhe {
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
 // spaces, i.e. s_waitcnt vmcnt(0): it would wait for the key rows prefetched across it.  Hand-offs here go through LDS.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef ABL_NOBAR      // timing ablation only (wrong results)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 template <int R>
@@ -141,7 +145,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     // last two refills of a step fetching rows 0, 1 of the next one.
     cplx bA[R], bB[R];
     auto fetch = [&](cplx (&dst)[R], int step, int rc) {
+#ifdef ABL_BKHOT      // timing ablation only (wrong results): every key row load hits the same (cache-resident) row
+        const cplx* src = a.bk + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + lane + 0 * step;
+#else
         const cplx* src = a.bk + (size_t)step * trgsw_cplx + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + lane;
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < R; m++) dst[m] = src[m * 64];
@@ -174,7 +182,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
         for (int mm = 0; mm < 2 * R; mm++) {
             const int c = ln + 64 * mm;
+#ifdef ABL_NOGATHER   // timing ablation only (wrong results)
+            u[mm] = ((own[mm] * (uint32_t)(r + c)) + M) ^ M;
+#else
             u[mm] = ((rotated_coef<LOGN>(poly, c, r) - own[mm]) + M) ^ M;
+#endif
         }
         PAIR_STAMP(0);
         double xr[L][R], xi[L][R];
@@ -185,12 +197,25 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
                 xr[jj][m] = (double)decomp_digit(u[m], BGBIT, jj);
                 xi[jj][m] = (double)decomp_digit(u[R + m], BGBIT, jj);
             }
+        }
+#ifdef PAIR_SEQUENTIAL_ROWS      // A/B: one transform after the other (round 1)
+#pragma unroll
+        for (int jj = 0; jj < L; jj++) {
             fft_forward_a<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
             prio_point(2 * jj);
             fft_forward_b<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
             prio_point(2 * jj + 1);
             PAIR_STAMP(1 + jj);
         }
+#else
+        // the three digit rows side by side: twiddles loaded once per pass, a row's exchange in flight under the next rows' passes
+        fft_forward_multi_a<LOGN, L>(xr, xi, twf, myx, myx + G::XSLOTS, ln);
+        prio_point(2);
+        PAIR_STAMP(1);
+        fft_forward_multi_b<LOGN, L>(xr, xi, twf);
+        prio_point(5);
+        PAIR_STAMP(3);
+#endif
 
         double sre[R], sim[R];
         auto zero = [&]() {
@@ -247,8 +272,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
-            own[m] = poly[c] + trunc_to_torus(sre[m]);          // kept for the gather that follows immediately
-            own[R + m] = poly[c + P] + trunc_to_torus(sim[m]);
+            own[m] += trunc_to_torus(sre[m]);                   // own[] IS this side's polynomial: no read-back; kept for the next gather
+            own[R + m] += trunc_to_torus(sim[m]);
             poly[c] = own[m];
             poly[c + P] = own[R + m];
         }
@@ -257,6 +282,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         PAIR_STAMP(9);
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef ABL_NOKS       // timing ablation only (wrong results): no sample extract / key switch
+    if (a.steps >= 0) return;
+#endif
 #ifdef RTFHE_WG_STAMPS
     if (a.dbg && blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 16; k++) a.dbg[wave * 16 + k] = tsum[k];

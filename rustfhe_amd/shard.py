@@ -81,7 +81,7 @@ class ShardedGates:
         lo, hi = parts[self.rank]
         t0 = time.perf_counter()
         if self.world == 1:
-            mine = [in0] + ([in1] if has_in1 else [])
+            mine = [t.to(self.device) for t in ([in0] + ([in1] if has_in1 else []))]
         else:
             fulls = ([in0] + ([in1] if has_in1 else [])) if self.rank == self.root else [None] * (2 if has_in1 else 1)
             mine = self._scatter(fulls, parts)
@@ -106,6 +106,9 @@ def engine_compute(engine, gpu=None):
     """compute callback running the HIP path on this rank's GPU.  Tensors arrive on the communication device: device
     tensors are used in place (nccl); CPU tensors (gloo rehearsal) are staged to `gpu` and back."""
     def fn(op, a, b):
+        nonlocal gpu
+        if gpu is None:
+            gpu = torch.device("cuda", engine.device)
         st = torch.cuda.current_stream().cuda_stream
         if a.is_cuda:
             out = torch.empty_like(a)

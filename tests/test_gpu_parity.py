@@ -273,3 +273,23 @@ def test_inverse_transform_beyond_2_pow_51(engine, orc, params):
     if vals is not None:
         assert np.abs(vals).max() < 2.0 ** 63 and np.abs(vals).max() > 2.0 ** 52      # in the reference's range, past the old one
     assert np.array_equal(res, exp)
+
+
+def test_dev_entry_points_refuse_host_pointers(engine, params, keys):
+    """A pageable host pointer handed to a *_dev call would make the kernel fault the GPU; the ABI checks what kind of memory
+    it was given and refuses before launching (pinned rtfhe_host_alloc memory is GPU-addressable and accepted)."""
+    import torch
+    import rustfhe_amd as R
+    c = keys.encrypt_bits([1, 0, 1])
+    d = torch.from_numpy(c.view(np.int32)).cuda()
+    out = torch.empty_like(d)
+    with pytest.raises(R.RtfheError) as ei:
+        engine.gate_batch_dev(R.NAND, int(c.ctypes.data), d, out, 3)
+    assert ei.value.code == R._ffi.ERR_INVALID and "device pointers" in str(ei.value)
+    with pytest.raises(R.RtfheError):
+        engine.gate_batch_dev(R.NAND, d, d, int(c.ctypes.data), 3)
+    pin = R.pinned_empty(c.shape)
+    pin[:] = c
+    engine.gate_batch_dev(R.NAND, int(pin.ctypes.data), d, out, 3)
+    engine.sync()
+    assert keys.decrypt_bits(out.cpu().numpy().view(np.uint32)) == [0, 1, 0]
