@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtfhe_hip.so")
 SOURCES = ["rtfhe_api.hip", "rtfhe_keygen.cpp", "rtfhe_wire.cpp"]
-DEPS = SOURCES + ["rtfhe_device.hpp", "rtfhe_kernels.hpp", "rtfhe_kernels_wg.hpp", "rtfhe_kernels_pair.hpp", "rtfhe_kernels_ntt.hpp", "rtfhe_ntt.hpp", os.path.join("..", "..", "include", "rtfhe.h")]
+DEPS = SOURCES + ["rtfhe_device.hpp", "rtfhe_kernels.hpp", "rtfhe_kernels_wg.hpp", "rtfhe_kernels_pair.hpp", "rtfhe_kernels_halves.hpp", "rtfhe_kernels_ntt.hpp", "rtfhe_ntt.hpp", os.path.join("..", "..", "include", "rtfhe.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
 

@@ -16,6 +16,7 @@
 #include "rtfhe_kernels.hpp"
 #include "rtfhe_kernels_wg.hpp"
 #include "rtfhe_kernels_pair.hpp"
+#include "rtfhe_kernels_halves.hpp"
 #include "rtfhe_kernels_ntt.hpp"
 
 using namespace rtfhe;
@@ -108,6 +109,49 @@ struct HostTw {
         get(fft_table + r, untw_c.data(), untw_s.data(), P);
     }
 
+    // table of k_bootstrap_halves (N = 2048; layout: HalvesTw): per direction the twist of the 16 inputs of a lane, the
+    // twiddles of the stage with halfnn = 512, and the 512-point sub-transform's stage tables in the geometry of Geo<10>.
+    // (The two directions cannot share one table: the reference's inverse entries are the conjugates of the forward ones except
+    // at the quarter turn of every stage, where cos is -6.1e-17 forward and +6.1e-17 inverse.)
+    std::vector<cplx> halves_table() const {
+        typedef Geo<10> G;
+        std::vector<cplx> t(HalvesTw::TOTAL);
+        const double fold = 2.0 / (double)N;      // the inverse's input scaling (fft_processor_spqlios.cpp:158), exact, folded into the untwist
+        for (int k = 0; k < 16; k++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int p = (k < 8) ? lane + 64 * k : 512 + lane + 64 * (k - 8);
+                t[HalvesTw::TWIST + k * 64 + lane] = make_double2(twist_c[p], twist_s[p]);
+                t[HalvesTw::IUNTW + k * 64 + lane] = make_double2(untw_c[p] * fold, untw_s[p] * fold);
+            }
+        for (int m = 0; m < 8; m++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int q = lane + 64 * m;
+                t[HalvesTw::ST1 + m * 64 + lane] = make_double2(fwd_c[fwd_off(512) + q], fwd_s[fwd_off(512) + q]);
+                t[HalvesTw::IST1 + m * 64 + lane] = make_double2(inv_c[inv_off(512) + q], inv_s[inv_off(512) + q]);
+            }
+        for (int mb = G::LR - 1; mb >= 0; mb--) {
+            const int h = 1 << mb;
+            for (int q = 0; q < h; q++) {
+                const int e = G::R - 2 * h + q;
+                for (int lane = 0; lane < 64; lane++) {           // pass 1: halfnn = 64 h
+                    const int idx = lane + 64 * q;
+                    t[HalvesTw::P1 + e * 64 + lane] = make_double2(fwd_c[fwd_off(64 * h) + idx], fwd_s[fwd_off(64 * h) + idx]);
+                    t[HalvesTw::IP1 + e * 64 + lane] = make_double2(inv_c[inv_off(64 * h) + idx], inv_s[inv_off(64 * h) + idx]);
+                }
+                for (int r = 0; r < G::NLOW; r++) {               // pass 2: halfnn = 8 h
+                    const int idx = (q << G::LOW) | r;
+                    t[HalvesTw::P2 + e * G::NLOW + r] = make_double2(fwd_c[fwd_off(G::NLOW * h) + idx], fwd_s[fwd_off(G::NLOW * h) + idx]);
+                    t[HalvesTw::IP2 + e * G::NLOW + r] = make_double2(inv_c[inv_off(G::NLOW * h) + idx], inv_s[inv_off(G::NLOW * h) + idx]);
+                }
+            }
+        }
+        for (int q = 0; q < 4; q++) {                             // pass 3: halfnn = 4
+            t[HalvesTw::P3 + q] = make_double2(fwd_c[fwd_off(4) + q], fwd_s[fwd_off(4) + q]);
+            t[HalvesTw::IP3 + q] = make_double2(inv_c[inv_off(4) + q], inv_s[inv_off(4) + q]);
+        }
+        return t;
+    }
+
     // device table: per direction [twist R*64][pass1 (R-1)*64][pass2 (R-1)*NLOW][pass3 NLOW-4]
     template <int LOGN>
     std::vector<cplx> device_table() const {
@@ -163,6 +207,8 @@ struct rtfhe_ctx {
     HostTw tw;
     cplx* d_tw = nullptr;
     cplx* d_bk = nullptr;
+    cplx* d_htw = nullptr;            // N = 2048: tables of k_bootstrap_halves
+    cplx* d_hbk = nullptr;            // N = 2048: key spectra in the halves layout
     int backend = RTFHE_BACKEND_FFT64_MIRROR;
     uint32_t* d_bk_torus = nullptr;   // kept when the key came in torus form: source for the NTT-domain key
     double* d_ntt_bk = nullptr;
@@ -270,6 +316,19 @@ int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return 0;
 }
 
+// N = 2048: two waves per transform (rtfhe_kernels_halves.hpp)
+int launch_bootstrap_halves11(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    constexpr int GATES = 4;
+    auto k = k_bootstrap_halves<3, 6, 8, 2, KSQ, GATES>;
+    const size_t lds = HalvesLds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    HalvesArgs a{b, ctx->d_htw, ctx->d_hbk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(128 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
 // `cnt` gates of a batch starting at gate `off` (plain batches advance the ciphertext pointers, netlist waves the index arrays)
 BootstrapArgs batch_segment(BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
     if (a.idx0) { a.ops += off; a.idx0 += off; a.idx1 += off; a.idx_out += off; }
@@ -303,7 +362,10 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         }
         return 0;
     } else {
-        return launch_bootstrap_w<11, 4>(ctx, a, s);   // inverse pass-1/untwist twiddles stay in global memory: 4 gates per CU fit
+        // two waves per transform (two waves per SIMD, no AGPR traffic); RTFHE_FORCE_WAVES=4 selects one wave per gate
+        // (inverse pass-1/untwist twiddles in global memory: 4 gates per CU fit)
+        if (ctx->d_htw && ctx->d_hbk && ctx->force_waves != 4) return launch_bootstrap_halves11(ctx, a, s);
+        return launch_bootstrap_w<11, 4>(ctx, a, s);
     }
 }
 
@@ -467,6 +529,23 @@ int upload_twiddles(rtfhe_ctx* ctx) {
     std::vector<cplx> t = ctx->logn == 10 ? ctx->tw.device_table<10>() : ctx->tw.device_table<11>();
     if (!ctx->d_tw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tw, t.size() * sizeof(cplx)));
     HIPCHECK(ctx, hipMemcpy(ctx->d_tw, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    if (ctx->logn == 11) {
+        std::vector<cplx> h = ctx->tw.halves_table();
+        if (!ctx->d_htw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_htw, h.size() * sizeof(cplx)));
+        HIPCHECK(ctx, hipMemcpy(ctx->d_htw, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// N = 2048: the key spectra once more in the layout of k_bootstrap_halves (derived from d_bk on this context's device)
+int build_halves_bk(rtfhe_ctx* ctx) {
+    if (ctx->logn != 11 || !ctx->d_bk) return 0;
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    const size_t polys = bk_word_count(ctx->p) / ctx->p.N;
+    if (!ctx->d_hbk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_hbk, bk_cplx_count(ctx->p) * sizeof(cplx)));
+    hipLaunchKernelGGL(k_bk_to_halves, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, ctx->d_hbk, polys, 1.0);
+    HIPCHECK(ctx, hipGetLastError());
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -477,7 +556,7 @@ int transform_bk_from_torus(rtfhe_ctx* ctx) {
     FftArgs a{ctx->d_tw, ctx->d_bk_torus, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l};
     if (int rc = launch_fft(ctx, true, a, ctx->stream)) return rc;
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return build_halves_bk(ctx);
 }
 
 int use(rtfhe_ctx* ctx) {
@@ -498,6 +577,7 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_ntt<3, 6, 8, 2, KSQ, 4>, ntt_lds_bytes(4, npad))) return rc;
     } else {
         if (int rc = allow_lds(ctx, k_bootstrap<11, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<11>(4, npad, bootstrap_dual_xbuf(11, 4)))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 4>, HalvesLds::bytes(4, npad))) return rc;
     }
     return 0;
 }
@@ -690,6 +770,8 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->d_bk) (void)hipFree(ctx->d_bk);
+    if (ctx->d_htw) (void)hipFree(ctx->d_htw);
+    if (ctx->d_hbk) (void)hipFree(ctx->d_hbk);
     if (ctx->d_bk_torus) (void)hipFree(ctx->d_bk_torus);
     if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
     if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);
@@ -752,6 +834,8 @@ int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
     for (rtfhe_ctx* peer : ctx->peers) {      // the transformed key and its torus form, device to device
         if (int rc = replicate(ctx, peer, ctx->d_bk, (void**)&peer->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx))) return rc;
         if (int rc = replicate(ctx, peer, ctx->d_bk_torus, (void**)&peer->d_bk_torus, words * 4)) return rc;
+        if (int rc = build_halves_bk(peer)) return fail(ctx, rc, peer->err);
+        HIPCHECK(ctx, hipSetDevice(ctx->device));
         peer->ntt_ready = false; peer->has_bk = true;
     }
     return 0;
@@ -770,10 +854,13 @@ int rtfhe_load_bk_fft(rtfhe_ctx* ctx, const double* bk_f) {
     if (rc) return rc;
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_bk_torus) { (void)hipFree(ctx->d_bk_torus); ctx->d_bk_torus = nullptr; }   // no torus form of this key
+    if (int rc = build_halves_bk(ctx)) return rc;
     ctx->ntt_ready = false;
     ctx->has_bk = true;
     for (rtfhe_ctx* peer : ctx->peers) {
         if (int rc = replicate(ctx, peer, ctx->d_bk, (void**)&peer->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx))) return rc;
+        if (int rc = build_halves_bk(peer)) return fail(ctx, rc, peer->err);
+        HIPCHECK(ctx, hipSetDevice(ctx->device));
         if (peer->d_bk_torus) { (void)hipSetDevice(peer->device); (void)hipFree(peer->d_bk_torus); peer->d_bk_torus = nullptr; (void)hipSetDevice(ctx->device); }
         peer->ntt_ready = false; peer->has_bk = true;
     }

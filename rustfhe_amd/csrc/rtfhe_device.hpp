@@ -96,7 +96,10 @@ __device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], c
 }
 
 // DIT, twiddled: t = x1 * w ; x0' = x0 + t ; x1' = x0 - t   (spqlios-fft-impl.cpp:346-359)
-template <int R, int MB>
+// CONJ: w holds the FORWARD table's (c, s) and the stage multiplies by its conjugate (c, -s) -- what the reference's inverse
+// table contains (the host checks the two tables are exact conjugates before a kernel relies on it).  x * (-s) == -(x * s)
+// and a - (-b) == a + b exactly, so t0 + t3 / t2 - t1 are the bits the reference's t0 - t3' / t1' + t2 give.
+template <int R, int MB, bool CONJ = false>
 __device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], const cplx* w) {
     constexpr int h = 1 << MB;
 #pragma unroll
@@ -104,7 +107,7 @@ __device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], c
         if (m & h) continue;
         const int m1 = m | h, q = m & (h - 1);
         const double t0 = re[m1] * w[q].x, t1 = re[m1] * w[q].y, t2 = im[m1] * w[q].x, t3 = im[m1] * w[q].y;
-        const double tr = t0 - t3, ti = t1 + t2;
+        const double tr = CONJ ? t0 + t3 : t0 - t3, ti = CONJ ? t2 - t1 : t1 + t2;
         const double ar = re[m], ai = im[m];
         re[m] = ar + tr; im[m] = ai + ti;
         re[m1] = ar - tr; im[m1] = ai - ti;
@@ -166,11 +169,12 @@ struct P12 {   // passes 1 and 2: all LR register bits, twiddled; w = the pass's
             P12<R, MBTOP - 1>::fwd(re, im, w);
         }
     }
+    template <bool CONJ = false>
     __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 0) {
             constexpr int h = 1 << MBTOP;
-            P12<R, MBTOP - 1>::inv(re, im, w);
-            inv_stage_tw<R, MBTOP>(re, im, w + (R - 2 * h));
+            P12<R, MBTOP - 1>::template inv<CONJ>(re, im, w);
+            inv_stage_tw<R, MBTOP, CONJ>(re, im, w + (R - 2 * h));
         }
     }
 };
@@ -187,11 +191,12 @@ struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uni
             stage_size2<R>(re, im);
         }
     }
+    template <bool CONJ = false>
     __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 2) {
             constexpr int h = 1 << MBTOP;
-            P3<R, NLOW, MBTOP - 1>::inv(re, im, w);
-            inv_stage_tw<R, MBTOP>(re, im, w + (NLOW - 2 * h));
+            P3<R, NLOW, MBTOP - 1>::template inv<CONJ>(re, im, w);
+            inv_stage_tw<R, MBTOP, CONJ>(re, im, w + (NLOW - 2 * h));
         } else {
             stage_size2<R>(re, im);
             inv_stage_size4<R>(re, im);
@@ -327,13 +332,14 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 // of a wave execute in order, so the rows may share the exchange buffers back to back without waiting for each other's reads.
 // Same butterflies, same operands, same order per row as fft_forward.
 // part A: twist, pass 1, first exchange, pass 2, second exchange (issued).  part B: pass 3.  in: layout L1, out: layout L3.
-template <int LOGN, int NR>
+// TWIST = false: the rows come already twisted (the two-waves-per-transform kernel twists before its first, cross-wave stage).
+template <int LOGN, int NR, bool TWIST = true>
 __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
                                                     const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {        // twist twiddles in two halves: R/2 of them live at a time
+    for (int half = 0; half < (TWIST ? 2 : 0); half++) {        // twist twiddles in two halves: R/2 of them live at a time
         cplx wt[R / 2];
 #pragma unroll
         for (int m = 0; m < R / 2; m++) wt[m] = tw[G::TW_TWIST + lane + 64 * (half * (R / 2) + m)];

@@ -1,0 +1,322 @@
+// rtfhe_kernels_halves.hpp -- the bootstrap kernel for N = 2048 with TWO WAVES PER TRANSFORM (BASELINE config 5).
+//
+// At N = 2048 a polynomial's transform has 1024 complex points: 16 per lane in one wavefront.  The one-wave-per-gate kernel
+// (k_bootstrap<11>) then needs 128 VGPRs of accumulators + 64 of spectrum + 128 of key rows, lives in 512 registers with
+// ~790 AGPR shuffles per step, and runs one wave per SIMD at the lone-wave FP64 issue rate (6.75 cycles/instruction).  A
+// split by digit rows as in k_bootstrap_pair does not fit either (three 1024-point spectra = 192 VGPRs).
+//
+// Here the two waves of a gate split every transform by its TOP index bit instead.  The reference's forward network is
+// decimation in frequency (spqlios-fft-impl.cpp:469-641): after the twist, its first stage (halfnn = P/2 = 512) pairs point
+// q with point q + 512; every later stage stays inside one half.  So
+//   wave A (half 0): twist both inputs, y[q] = x0 + x1            -> 512-point sub-transform -> spectrum points [0, 512)
+//   wave B (half 1): twist both inputs, y[q] = (x0 - x1) * w_q    -> 512-point sub-transform -> spectrum points [512, 1024)
+// with the sub-transform exactly the 512-point network of the N = 1024 kernels (8 points per lane, three in-register passes,
+// two wave-private LDS exchanges; stage twiddles depend on 2 halfnn only).  Both waves gather and twist all 16 inputs a lane
+// needs (48 extra FP64 instructions per row: the price of never synchronising inside a forward transform).  Each wave then
+// owns ITS HALF of the points for the multiply-accumulate over all six rows and both components: the fold order
+// (trgsw.rs:290-299) holds trivially, no partial sums travel.  The inverse network is decimation in time
+// (spqlios-fft-impl.cpp:204-397): each wave runs the sub-network (halfnn = 1 .. 256) on its half, then the last stage
+// (halfnn = 512: t = x1 * w, x0 + t, x0 - t) needs the other half: wave B sends t, wave A sends x0 through their exchange
+// buffers, two LDS-only barriers per component.  Untwist, truncate, += into the LDS accumulator as everywhere else.
+//
+// Registers: three rows of one polynomial side by side (96 VGPRs of half-spectra) + 64 of accumulators + a two-buffer key-row
+// ring (64): 248, two waves per SIMD, four gates per CU.  LDS: 16 KiB of accumulator per gate leave room for the forward
+// sub-transform's stage tables (16 KiB) and the inverse's small ones (1 KiB) only: the twist / untwist tables and the inverse's
+// first-stage and pass-1 tables are read from global memory (once per polynomial / once per inverse: 2 inverses per step vs
+// 6 forward rows).  (One table cannot serve both directions: the reference's inverse table is the conjugate of the forward one
+// EXCEPT at the quarter-turn entry of every stage, where cos comes out as -6.1e-17 forward and +6.1e-17 inverse.)
+// The 2/N input scaling of fft_processor_spqlios.cpp:158 is folded into the untwist table as in the other kernels.
+#pragma once
+
+#include "rtfhe_kernels_pair.hpp"
+
+#ifndef HALVES_PRIO_B
+#define HALVES_PRIO_B 1      // wave B carries ~9 % more arithmetic (the first-stage / last-stage twiddle products)
+#endif
+
+namespace rtfhe {
+
+// twiddle table of the halves kernel, cplx units: forward part, then inverse part
+struct HalvesTw {
+    static constexpr int TWIST = 0;                 // [16][64]: k < 8: point lane + 64 k; k >= 8: point 512 + lane + 64 (k - 8)   (global memory)
+    static constexpr int ST1 = TWIST + 16 * 64;     // [8][64]:  first-stage twiddle (halfnn = 512) of pair q = lane + 64 m          (LDS from here ...
+    static constexpr int P1 = ST1 + 8 * 64;         // [7][64]   sub-transform, as Geo<10>
+    static constexpr int P2 = P1 + 7 * 64;          // [7][8]
+    static constexpr int P3 = P2 + 7 * 8;           // [4]                                                                            ... to here)
+    static constexpr int IUNTW = P3 + 4;            // [16][64]  untwist, times 2/N                                                  (global memory)
+    static constexpr int IST1 = IUNTW + 16 * 64;    // [8][64]   last-stage twiddle (halfnn = 512)                                   (global memory)
+    static constexpr int IP1 = IST1 + 8 * 64;       // [7][64]                                                                        (global memory)
+    static constexpr int IP2 = IP1 + 7 * 64;        // [7][8]                                                                         (LDS from here ...
+    static constexpr int IP3 = IP2 + 7 * 8;         // [4]                                                                            ... to here)
+    static constexpr int TOTAL = IP3 + 4;
+    static constexpr int LDS_FWD = IUNTW - ST1;     // forward ST1 .. P3
+    static constexpr int LDS_INV = TOTAL - IP2;     // inverse IP2 .. IP3
+    static constexpr int LDS_CPLX = LDS_FWD + LDS_INV;
+};
+
+struct HalvesLds {
+    typedef Geo<10> G;   // geometry of the 512-point sub-transform
+    static constexpr size_t TW = (size_t)HalvesTw::LDS_CPLX * sizeof(cplx);
+    static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers: hold 512 cplx
+    __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB; }
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
+};
+
+struct HalvesArgs {
+    BootstrapArgs b;       // b.tw / b.bk unused
+    const cplx* htw;       // [HalvesTw::TOTAL]
+    const cplx* hbk;       // [n][2l rows][2 comp][2 half][8][64]
+};
+
+// key spectra: device layout of k_bootstrap<11> ([n][row][comp][16][64]: lane v, register m <-> point (v << 4) | m) ->
+// halves layout (lane v, register m of half H <-> point (H << 9) | (v << 3) | m)
+__global__ __launch_bounds__(256) void k_bk_to_halves(const cplx* __restrict__ src, cplx* __restrict__ dst, size_t polys, double scale) {
+    const size_t total = polys * 1024;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = idx >> 10;
+        const int k = (int)(idx & 1023);                 // destination: (H, m, lane)
+        const int H = k >> 9, m = (k >> 6) & 7, lane = k & 63;
+        const int p = (H << 9) | (lane << 3) | m;
+        const cplx v = src[g * 1024 + (size_t)(p & 15) * 64 + (p >> 4)];
+        dst[idx] = make_double2(v.x * scale, v.y * scale);
+    }
+}
+
+template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
+__global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const HalvesArgs ha) {
+    constexpr int LOGN = 11, N = 2048, P = 1024, R = 8, NT = 128 * GATES;
+    typedef Geo<10> G;   // the 512-point sub-transform
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    static_assert(L == 3, "three digit rows of a polynomial are transformed side by side");
+    const BootstrapArgs& a = ha.b;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave % GATES, H = wave / GATES;          // the two halves of a gate share a SIMD (waves w, w + GATES)
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    for (int idx = tid; idx < HalvesTw::LDS_FWD; idx += NT) tw[idx] = ha.htw[HalvesTw::ST1 + idx];
+    for (int idx = tid; idx < HalvesTw::LDS_INV; idx += NT) tw[HalvesTw::LDS_FWD + idx] = ha.htw[HalvesTw::IP2 + idx];
+    const cplx* tw_st1 = tw;
+    const cplx* tw_sub = tw + (HalvesTw::P1 - HalvesTw::ST1) - G::TW_P1;   // so that tw_sub + G::TW_P1/P2/P3 address the sub-transform tables
+    const cplx* twi_small = tw + HalvesTw::LDS_FWD - G::TW_P2;            // twi_small + G::TW_P2/P3: the inverse's pass-2/3 tables
+    static_assert(HalvesTw::P2 - HalvesTw::P1 == G::TW_P2 - G::TW_P1 && HalvesTw::P3 - HalvesTw::P2 == G::TW_P3 - G::TW_P2 &&
+                  HalvesTw::IP3 - HalvesTw::IP2 == G::TW_P3 - G::TW_P2, "same table geometry as Geo<10>");
+    const cplx* gtwist0 = ha.htw + HalvesTw::TWIST;           // [16][64] in global memory
+    const cplx* guntw0 = ha.htw + HalvesTw::IUNTW;            // [16][64]
+    const cplx* gist10 = ha.htw + HalvesTw::IST1;             // [8][64]
+    const cplx* gip10 = ha.htw + HalvesTw::IP1;               // [7][64]
+
+    const int g_raw = blockIdx.x * GATES + slot;
+    const int g = g_raw < a.count ? g_raw : a.count - 1;
+    const GateIo io = gate_io(a, g);
+    const bool live = g_raw < a.count && io.ok;
+
+    unsigned char* gbase = smem + HalvesLds::TW + (size_t)slot * HalvesLds::gate_bytes(a.npad);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
+    uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
+    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + HalvesLds::abar_bytes(a.npad));
+    double* xb1 = xb0 + 2 * G::XSLOTS;
+    double* myx = H ? xb1 : xb0;
+    double* otx = H ? xb0 : xb1;
+
+    const int n = a.n;
+    {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane0 + 64 * H; i <= n; i += 128) {
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
+            abar[i] = (uint16_t)((i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH));
+        }
+    }
+    __syncthreads();
+    {   // acc = X^{-bbar} * testvec (tfhe.rs:85, 98-106); each wave initialises half of the words
+        const int bbar = (int)abar[n];
+        for (int c = lane0 + 64 * H; c < 2 * N; c += 128) {
+            const int e = (c + bbar) & (2 * N - 1);
+            accbuf[c] = c < N ? ((e >> LOGN) ? 0xE0000000u : 0x20000000u) : 0u;
+        }
+    }
+    __syncthreads();
+
+    // key rows in consumption order rc = 0..11: (row rc / 2, component rc & 1) of this half.  Two buffers: the first two rows of a
+    // polynomial are requested once its decomposition words are dead (after the first stage), the others as a buffer retires
+    const size_t trgsw_cplx = (size_t)2 * L * 2 * 2 * R * 64;
+    cplx bA[R], bB[R];
+    auto fetch = [&](cplx (&dst)[R], int step, int rc) {
+        const cplx* src = ha.hbk + (size_t)step * trgsw_cplx + (size_t)((rc >> 1) * 2 + (rc & 1)) * 2 * R * 64 + (size_t)H * R * 64 + lane0;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < R; m++) dst[m] = src[m * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (H) __builtin_amdgcn_s_setprio(HALVES_PRIO_B);
+
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        double s0re[R], s0im[R], s1re[R], s1im[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { s0re[m] = 0.0; s0im[m] = 0.0; s1re[m] = 0.0; s1im[m] = 0.0; }
+
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t* poly = accbuf + h * N;
+            int ln = lane0;
+            asm volatile("" : "+v"(ln));        // keeps the lane-derived LDS addresses from being hoisted out of the loops and spilled
+            // the 16 complex inputs of this lane are points q and q + 512, q = lane + 64 m: coefficients q + 512 k, k = 0..3
+            // (k = 0: Re x0, 1: Re x1, 2: Im x0, 3: Im x1)   (rotate: math.rs:85-132; decomposition: math.rs:300-326).
+            // Gather, decomposition, twist (spqlios-fft-impl.cpp:512-517) and first stage (:546-569) of the three digit rows go
+            // point by point: only one point's decomposition words and twiddles are live at a time.
+            double yr[L][R], yi[L][R];
+            const cplx* gtwist = gtwist0 + ln;
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                uint32_t u[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = ln + 64 * m + 512 * k;
+                    u[k] = ((rotated_coef<LOGN>(poly, c, r) - poly[c]) + M) ^ M;
+                }
+                const cplx t0 = gtwist[m * 64], t1 = gtwist[(8 + m) * 64], w1 = tw_st1[m * 64 + ln];
+#pragma unroll
+                for (int jj = 0; jj < L; jj++) {
+                    const double a0 = (double)decomp_digit(u[0], BGBIT, jj), b0 = (double)decomp_digit(u[2], BGBIT, jj);
+                    const double a1 = (double)decomp_digit(u[1], BGBIT, jj), b1 = (double)decomp_digit(u[3], BGBIT, jj);
+                    const double rc0 = a0 * t0.x, ic0 = b0 * t0.x, rs0 = a0 * t0.y, is0 = b0 * t0.y;
+                    const double x0r = rc0 - is0, x0i = ic0 + rs0;
+                    const double rc1 = a1 * t1.x, ic1 = b1 * t1.x, rs1 = a1 * t1.y, is1 = b1 * t1.y;
+                    const double x1r = rc1 - is1, x1i = ic1 + rs1;
+                    if (H == 0) {
+                        yr[jj][m] = x0r + x1r; yi[jj][m] = x0i + x1i;
+                    } else {
+                        const double dr = x0r - x1r, di = x0i - x1i;
+                        double p = dr * w1.x, q = di * w1.y;
+                        yr[jj][m] = p - q;
+                        p = dr * w1.y; q = di * w1.x;
+                        yi[jj][m] = p + q;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one point at a time: keeps the gather of later points from being hoisted
+            }
+            // the 512-point sub-transforms of the three rows side by side
+            fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, myx, myx + G::XSLOTS, ln);
+#ifndef HALVES_FETCH_LATE
+            fetch(bA, i, h * 2 * L);                    // (row 0, comp 0) of this polynomial: in flight under the last pass
+#endif
+            fft_forward_multi_b<10, L>(yr, yi, tw_sub);
+#ifdef HALVES_FETCH_LATE
+            fetch(bA, i, h * 2 * L);
+#endif
+            // hadamard + fold-add (spqlios.rs:204-222, trgsw.rs:290-299): this wave's half of the points, component 0 over the
+            // polynomial's three rows, then component 1 (each accumulator still folds rows 0..5 in order); two key-row buffers,
+            // each refilled as soon as its multiply-accumulate has retired
+            const int rc0 = h * 2 * L;                  // rc = 2 * row + comp
+            fetch(bB, i, rc0 + 2);                                                     // (row 1, c0)
+            mac_row<R>(s0re, s0im, bA, yr[0], yi[0]); fetch(bA, i, rc0 + 4);           // (row 2, c0)
+            mac_row<R>(s0re, s0im, bB, yr[1], yi[1]); fetch(bB, i, rc0 + 1);           // (row 0, c1)
+            mac_row<R>(s0re, s0im, bA, yr[2], yi[2]); fetch(bA, i, rc0 + 3);           // (row 1, c1)
+            mac_row<R>(s1re, s1im, bB, yr[0], yi[0]); fetch(bB, i, rc0 + 5);           // (row 2, c1)
+            mac_row<R>(s1re, s1im, bA, yr[1], yi[1]);
+            mac_row<R>(s1re, s1im, bB, yr[2], yi[2]);
+        }
+
+        // inverse: sub-network on this half, last stage across the halves, untwist, truncate, += acc
+#pragma unroll 1
+        for (int comp = 0; comp < 2; comp++) {
+            double re[R], im[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) { re[m] = comp ? s1re[m] : s0re[m]; im[m] = comp ? s1im[m] : s0im[m]; }
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));      // as above: addresses are re-derived here instead of living (spilled) across the step
+            {
+                Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1;
+                w1.load(gip10 + lane, 64);                  // global memory: requested first, used last
+                w3.load(twi_small + G::TW_P3, 1);
+                P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
+                w2.load(twi_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+                exchange<10, 3, 2, true>(re, im, myx, lane);
+                P12<R, G::LR - 1>::inv(re, im, w2.w);
+                exchange<10, 2, 1, true>(re, im, myx, lane);
+                P12<R, G::LR - 1>::inv(re, im, w1.w);
+            }
+            // now lane holds sub-points q = lane + 64 m of its half.  Last stage (halfnn = 512, spqlios-fft-impl.cpp:346-359):
+            // t = x1 * w_q; half 0 keeps x0 + t, half 1 keeps x0 - t.  B sends t, A sends x0.
+            if (H == 1) {
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const cplx w = gist10[m * 64 + lane];
+                    const double t0 = re[m] * w.x, t1 = re[m] * w.y, t2 = im[m] * w.x, t3 = im[m] * w.y;
+                    re[m] = t0 - t3; im[m] = t1 + t2;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < R; m++) { myx[lane + 64 * m] = re[m]; myx[G::XSLOTS + lane + 64 * m] = im[m]; }
+            Tw<R> wt;      // untwist (times 2/N) of this half's points, from global memory: in flight across the barrier
+#pragma unroll
+            for (int m = 0; m < R; m++) wt.w[m] = guntw0[(H * 8 + m) * 64 + lane];
+            lds_barrier();
+            {
+                uint32_t* poly = accbuf + comp * N;
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const double orr = otx[lane + 64 * m], oi = otx[G::XSLOTS + lane + 64 * m];
+                    const double vr = H ? orr - re[m] : re[m] + orr;          // A: x0 + t, B: x0 - t
+                    const double vi = H ? oi - im[m] : im[m] + oi;
+                    // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395)
+                    const double rc = vr * wt.w[m].x, ic = vi * wt.w[m].x, rs = vr * wt.w[m].y, is = vi * wt.w[m].y;
+                    const int c = lane + 64 * m + 512 * H;
+                    poly[c] += trunc_to_torus(rc - is);
+                    poly[c + P] += trunc_to_torus(ic + rs);
+                }
+            }
+            lds_barrier();     // the partner has read my buffer; both halves of the accumulator are written
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        if (live) {
+            uint32_t* o = a.out + (size_t)g * 2 * N;
+            for (int c = lane0 + 64 * H; c < 2 * N; c += 128) o[c] = accbuf[c];
+        }
+        return;
+    }
+
+    // sample extract index 0 (trlwe.rs:110-121): a'_0 = a_0, a'_k = -a_{N-k}; b' = b_0
+    {
+        uint32_t av[2 * R];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) av[mm] = accbuf[N + lane0 + 64 * mm + 1024 * H];
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = lane0 + 64 * mm + 1024 * H;
+            accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[mm] : (0u - av[mm]);
+        }
+    }
+    __syncthreads();
+    // identity key switch (tlwe.rs:43-73): each wave sums the rows of half of the coefficients
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, H * (N / 2), (H + 1) * (N / 2), a.ksk, a.ksw, sum, lane0);
+    uint4* part = reinterpret_cast<uint4*>(xb1) + lane0;   // [KSQ][64] uint4
+    if (H == 1) {
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) part[q * 64] = sum[q];
+    }
+    __syncthreads();
+    if (H == 0 && live) {
+        const uint32_t bprime = accbuf[0];
+        uint32_t* out = io.out;
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) {
+            const uint4 o = part[q * 64];
+            const int col = 4 * (lane0 + 64 * q);
+            const uint32_t s[4] = {sum[q].x + o.x, sum[q].y + o.y, sum[q].z + o.z, sum[q].w + o.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (col + e <= n) out[col + e] = ((col + e == n) ? bprime : 0u) - s[e];
+        }
+    }
+}
+
+}  // namespace rtfhe

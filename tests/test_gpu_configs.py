@@ -227,3 +227,27 @@ def test_key_file_feeds_an_engine(tmp_path, params, keys, gold_gate):
     R.save_tlwe(cts, q, out)
     assert np.array_equal(R.load_tlwe(cts), out)
     e.close()
+
+
+def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch):
+    """N = 2048: the two-waves-per-transform kernel (default) and the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4) are the
+    same arithmetic: identical words for a ragged batch, and for blind-rotate prefixes (both compared with the oracle above)."""
+    import rustfhe_amd as R
+    P, K, e = setup2048
+    rng = np.random.default_rng(2048)
+    b0, b1 = rng.integers(0, 2, 37), rng.integers(0, 2, 37)
+    c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
+    monkeypatch.setenv("RTFHE_FORCE_WAVES", "4")
+    one = R.Engine(R.Params(N=2048), 0)
+    monkeypatch.delenv("RTFHE_FORCE_WAVES")
+    try:
+        one.load_bk_torus(K.bk_t)
+        one.load_ksk(K.ksk)
+        for op in (R.NAND, R.OR, R.NOT):
+            assert np.array_equal(e.gate_batch(op, c0, c1), one.gate_batch(op, c0, c1))
+        t = np.stack([orc.gate_linear(P, orc.XOR, x, y) for x, y in zip(c0[:5], c1[:5])])
+        for steps in (0, 1, 2, 9):
+            assert np.array_equal(e.blind_rotate_batch(t, steps), one.blind_rotate_batch(t, steps))
+        assert K.decrypt_bits(e.gate_batch(R.NAND, c0, c1)) == list(1 - (b0 & b1))
+    finally:
+        one.close()

@@ -174,3 +174,4 @@ def test_ntt_backend_model():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ntt", "model.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
