@@ -196,7 +196,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                         yi[jj][m] = p + q;
                     }
                 }
+#ifndef HALVES_NO_POINT_BARRIER
                 __builtin_amdgcn_sched_barrier(0);      // one point at a time: keeps the gather of later points from being hoisted
+#endif
             }
             // the 512-point sub-transforms of the three rows side by side
             fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, myx, myx + G::XSLOTS, ln);
@@ -273,6 +275,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
         }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef ABL_NOKS       // timing ablation only (wrong results)
+    if (a.steps >= 0) return;
+#endif
+#ifdef ABL_NOGATHER
+#error "not wired for this kernel"
+#endif
 
     if (a.mode == MODE_BLIND_ROTATE) {
         if (live) {

@@ -10,7 +10,7 @@ import rustfhe_amd as R
 from rustfhe_amd import _ffi
 
 G, rounds, libs = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3:]
-P = R.Params()
+P = R.Params(N=int(os.environ.get('RTFHE_N', '1024')))
 key0, key1, bk, ksk = R.keygen(P, 20211003)
 rng = np.random.default_rng(0)
 b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
