@@ -174,7 +174,7 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
 constexpr int KS_GROUP = 2;
 __host__ __device__ constexpr int ks_dev_rows(int N, int t, int basebit) { return N * (t / KS_GROUP) * ((1 << (basebit * KS_GROUP)) - 1); }
 
-template <int LOGN, int KS_T, int KS_BB, int KSQ>
+template <int LOGN, int KS_T, int KS_BB, int KSQ, int KS_UI = 4>
 __device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprime, int i_begin, int i_end,
                                               const uint32_t* __restrict__ ksk, int ksw, uint4 (&sum)[KSQ], int lane) {
     constexpr int N = 1 << LOGN;
@@ -186,8 +186,7 @@ __device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprim
     int idx[KSQ];
 #pragma unroll
     for (int q = 0; q < KSQ; q++) { sum[q] = make_uint4(0, 0, 0, 0); idx[q] = min(lane + 64 * q, ksw / 4 - 1); }
-    // KS_UI coefficients per iteration: KS_UI * PT rows (3 x 16 B per lane each) in flight per wave
-    constexpr int KS_UI = 4;
+    // KS_UI coefficients per iteration: KS_UI * PT rows (3 x 16 B per lane each) in flight per wave (4 by default: 192 VGPRs)
 #pragma unroll 1
     for (int i = i_begin; i < i_end; i += KS_UI) {
         uint4 v[KS_UI][PT][KSQ];
