@@ -76,6 +76,9 @@ extern "C" {
     pub fn rtfhe_key_switch_batch(ctx: *mut rtfhe_ctx, tlwe1: *const u32, out: *mut u32, count: usize) -> c_int;
     pub fn rtfhe_ifft_i32_batch(ctx: *mut rtfhe_ctx, src: *const i32, res: *mut f64, count: usize) -> c_int;
     pub fn rtfhe_fft_u32_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_ifft_f64_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut f64, count: usize) -> c_int;
+    pub fn rtfhe_fft_f64_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut f64, count: usize) -> c_int;
+    pub fn rtfhe_poly_mul_batch(ctx: *mut rtfhe_ctx, a: *const u32, b: *const u32, res: *mut u32, count: usize) -> c_int;
 
     // production: randomness from the OS CSPRNG (like the reference's thread_rng)
     pub fn rtfhe_keygen(p: *const rtfhe_params, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;

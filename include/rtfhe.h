@@ -22,6 +22,8 @@
  *   rtfhe_key_switch_batch           <- TLWERep::identity_key_switch (hom_nand/src/tlwe.rs:43-73)
  *   rtfhe_ifft_i32_batch             <- Spqlios_ifft_i32 / _u32 (utils/src/spqlios.rs:22-23, spqlios-wrapper.cpp:22-28)
  *   rtfhe_fft_u32_batch              <- Spqlios_fft_u32 (utils/src/spqlios.rs:25, spqlios-wrapper.cpp:34-36)
+ *   rtfhe_ifft_f64_batch / _fft_f64_batch / _poly_mul_batch
+ *                                    <- Spqlios_ifft / Spqlios_fft / Spqlios_poly_mul (spqlios-wrapper.cpp:18-20,30-32,38-53)
  *   rtfhe_keys_* / rtfhe_tlwe_write/read  (no reference counterpart: it has no serialization; fixes App. A's layouts into files)
  *   rtfhe_keygen / rtfhe_tlwe_*      <- TFHE::new, Cryptor::encrypto/decrypto(TLWE, ..) (tfhe.rs:21-25, tlwe.rs:213-241);
  *                                       randomness from the OS CSPRNG like the reference's thread_rng; *_deterministic = seeded, TEST ONLY
@@ -162,6 +164,10 @@ int rtfhe_key_switch_batch(rtfhe_ctx *ctx, const uint32_t *tlwe1 /* [count][N+1]
                            uint32_t *out /* [count][n+1] */, size_t count);
 int rtfhe_ifft_i32_batch(rtfhe_ctx *ctx, const int32_t *src /* [count][N] */, double *res /* [count][N] */, size_t count);
 int rtfhe_fft_u32_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, uint32_t *res /* [count][N] */, size_t count);
+/* the rest of the reference's FFT FFI (off the gate path; utils/src/spqlios.rs:18-32, only its N = 16 unit test uses poly_mul) */
+int rtfhe_ifft_f64_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, double *res /* [count][N] */, size_t count);
+int rtfhe_fft_f64_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, double *res /* [count][N], no truncation */, size_t count);
+int rtfhe_poly_mul_batch(rtfhe_ctx *ctx, const uint32_t *a, const uint32_t *b, uint32_t *res /* [count][N] each */, size_t count);
 
 /* ---- key generation / encryption (host side) ----
  * Production entry points draw every key bit, mask and noise sample from the OS CSPRNG (getrandom(2), expanded with ChaCha20),

@@ -69,6 +69,9 @@ _SIGNATURES = {
     "rtfhe_key_switch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_ifft_i32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_fft_u32_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_ifft_f64_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_f64_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_poly_mul_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_keygen": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_keygen_with_keys": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -305,8 +305,8 @@ int launch_bootstrap_wg10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return 0;
 }
 
-int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    constexpr int GATES = 4;
+template <int GATES>
+int launch_bootstrap_pair10_g(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     auto k = k_bootstrap_pair<3, 6, 8, 2, KSQ, GATES>;
     const size_t lds = PairLds::bytes(GATES, a.npad);
     if (int rc = allow_lds(ctx, k, lds)) return rc;
@@ -315,6 +315,7 @@ int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     ctx->launches++;
     return 0;
 }
+int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return launch_bootstrap_pair10_g<4>(ctx, a, s); }
 
 // N = 2048: two waves per transform (rtfhe_kernels_halves.hpp)
 int launch_bootstrap_halves11(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
@@ -339,8 +340,10 @@ BootstrapArgs batch_segment(BootstrapArgs a, size_t off, size_t cnt, size_t out_
 
 // Kernel shape by batch size (N = 1024), measured in profiles/r01_pair/shape_sweep.log:
 //   whole rounds of 4 gates per CU : two waves per gate, 8-wave workgroups (k_bootstrap_pair) -- best throughput at every size
-//   a remainder <= wg_max (2 gates per CU) : one gate per 8-wave workgroup (k_bootstrap_wg): ~2.3x lower latency
-//   a larger remainder             : one more (partly filled) two-waves-per-gate round
+//   a remainder <= 1 gate per CU   : one gate per 8-wave workgroup (k_bootstrap_wg): ~2.4x lower latency
+//   a remainder <= 2 / 3 gates per CU : the two-waves-per-gate kernel with 2 / 3 gates per workgroup, one workgroup per CU -- every
+//                                    gate still has its two waves, which then share their SIMDs with fewer (or no) other waves
+//   a larger remainder             : one more (partly filled) round of 4 gates per CU
 // The segments are queued back to back on the caller's stream.  RTFHE_FORCE_WAVES=1|2|4|8 forces one shape for the
 // whole batch (4, 8: one gate per wave in 4- / 8-wave workgroups).
 template <int LOGN>
@@ -358,7 +361,10 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
             if (int rc = launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
         if (rem) {
             const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
-            return rem <= (size_t)ctx->wg_max ? launch_bootstrap_wg10(ctx, tail, s) : launch_bootstrap_pair10(ctx, tail, s);
+            if (rem <= (size_t)ctx->wg_max) return launch_bootstrap_wg10(ctx, tail, s);
+            if (rem <= (size_t)2 * ctx->num_cus) return launch_bootstrap_pair10_g<2>(ctx, tail, s);
+            if (rem <= (size_t)3 * ctx->num_cus) return launch_bootstrap_pair10_g<3>(ctx, tail, s);
+            return launch_bootstrap_pair10(ctx, tail, s);
         }
         return 0;
     } else {
@@ -553,10 +559,24 @@ int build_halves_bk(rtfhe_ctx* ctx) {
 // device copy of the torus-form key into the device spectra
 int transform_bk_from_torus(rtfhe_ctx* ctx) {
     const size_t words = bk_word_count(ctx->p);
-    FftArgs a{ctx->d_tw, ctx->d_bk_torus, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l};
+    FftArgs a{ctx->d_tw, ctx->d_bk_torus, ctx->d_bk, (int32_t)(words / ctx->p.N), 1, 2 * ctx->p.l, 0};
     if (int rc = launch_fft(ctx, true, a, ctx->stream)) return rc;
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     return build_halves_bk(ctx);
+}
+
+template <int LOGN>
+int launch_poly_mul_t(rtfhe_ctx* ctx, PolyMulArgs a, hipStream_t s) {
+    constexpr int W = 4;
+    typedef Geo<LOGN> G;
+    auto k = k_poly_mul<LOGN, W>;
+    const size_t lds = (size_t)G::TW_TOTAL * sizeof(cplx) + (size_t)W * G::XSLOTS * sizeof(double);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    int grid = (a.count + W - 1) / W;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    return 0;
 }
 
 int use(rtfhe_ctx* ctx) {
@@ -570,6 +590,8 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
     const int npad = (ctx->p.n + 1 + 63) / 64 * 64;
     if (ctx->logn == 10) {
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 4>, PairLds::bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 3>, PairLds::bytes(3, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 2>, PairLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_wg<10, 3, 6, 8, 2, KSQ>, WgLds<10, 3>::bytes(npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<10>(4, npad, bootstrap_dual_xbuf(10, 4)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 8>, bootstrap_lds_bytes<10>(8, npad, bootstrap_dual_xbuf(10, 8)))) return rc;
@@ -699,7 +721,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
     if (!rc) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
-        ctx->wg_max = 2 * ctx->num_cus;
+        ctx->wg_max = ctx->num_cus;
         if (const char* e = std::getenv("RTFHE_FORCE_WAVES")) ctx->force_waves = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_WG_MAX_GATES")) ctx->wg_max = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_STAGING")) ctx->stage_pinned = std::atoi(e) != 0;
@@ -1164,17 +1186,17 @@ int rtfhe_key_switch_batch(rtfhe_ctx* ctx, const uint32_t* tlwe1, uint32_t* out,
     return 0;
 }
 
-static int run_fft_batch(rtfhe_ctx* ctx, bool forward, const void* src, void* res, size_t count) {
+static int run_fft_batch(rtfhe_ctx* ctx, bool forward, bool f64_io, const void* src, void* res, size_t count) {
     if (int rc = use(ctx)) return rc;
     if (!src || !res) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (count == 0) return 0;
     if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
     const size_t N = (size_t)ctx->p.N;
-    const size_t in_bytes = count * N * (forward ? 4 : 8), out_bytes = count * N * (forward ? 8 : 4);
+    const size_t in_bytes = count * N * ((forward && !f64_io) ? 4 : 8), out_bytes = count * N * ((forward || f64_io) ? 8 : 4);
     if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, in_bytes)) return rc;
     if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, out_bytes)) return rc;
     HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    FftArgs a{ctx->d_tw, ctx->d_a, ctx->d_c, (int32_t)count, 0, 0};
+    FftArgs a{ctx->d_tw, ctx->d_a, ctx->d_c, (int32_t)count, 0, 0, f64_io ? 1 : 0};
     if (int rc = launch_fft(ctx, forward, a, ctx->stream)) return rc;
     HIPCHECK(ctx, hipMemcpyAsync(res, ctx->d_c, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1182,11 +1204,38 @@ static int run_fft_batch(rtfhe_ctx* ctx, bool forward, const void* src, void* re
 }
 
 int rtfhe_ifft_i32_batch(rtfhe_ctx* ctx, const int32_t* src, double* res, size_t count) {
-    return run_fft_batch(ctx, true, src, res, count);
+    return run_fft_batch(ctx, true, false, src, res, count);
 }
 
 int rtfhe_fft_u32_batch(rtfhe_ctx* ctx, const double* src, uint32_t* res, size_t count) {
-    return run_fft_batch(ctx, false, src, res, count);
+    return run_fft_batch(ctx, false, false, src, res, count);
+}
+
+int rtfhe_ifft_f64_batch(rtfhe_ctx* ctx, const double* src, double* res, size_t count) {
+    return run_fft_batch(ctx, true, true, src, res, count);
+}
+
+int rtfhe_fft_f64_batch(rtfhe_ctx* ctx, const double* src, double* res, size_t count) {
+    return run_fft_batch(ctx, false, true, src, res, count);
+}
+
+int rtfhe_poly_mul_batch(rtfhe_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* res, size_t count) {
+    if (int rc = use(ctx)) return rc;
+    if (!a || !b || !res) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    if (count > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "count too large");
+    const size_t bytes = count * (size_t)ctx->p.N * 4;
+    if (int rc = ensure(ctx, &ctx->d_a, &ctx->cap_a, bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_b, &ctx->cap_b, bytes)) return rc;
+    if (int rc = ensure(ctx, &ctx->d_c, &ctx->cap_c, bytes)) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_b, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PolyMulArgs pa{ctx->d_tw, (const uint32_t*)ctx->d_a, (const uint32_t*)ctx->d_b, (uint32_t*)ctx->d_c, (int32_t)count};
+    int rc = ctx->logn == 10 ? launch_poly_mul_t<10>(ctx, pa, ctx->stream) : launch_poly_mul_t<11>(ctx, pa, ctx->stream);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(res, ctx->d_c, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 }  // extern "C"

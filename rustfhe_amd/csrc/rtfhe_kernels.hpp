@@ -358,6 +358,7 @@ struct FftArgs {
     int32_t count;
     int32_t dst_layout;   // forward: 0 = FrrSeries (Re[0..P) | Im[0..P)), 1 = device BK layout [R][64] cplx
     int32_t rows;         // dst_layout 1: 2l; source polys ordered [i][comp][row], device polys [i][row][comp]
+    int32_t f64_io;       // forward: the source is double[count][N] (Spqlios_ifft); inverse: the result is double[count][N] (Spqlios_fft)
 };
 
 // source poly index (i, comp, row) -> device poly index (i, row, comp)
@@ -379,10 +380,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_forward(const FftArgs a) 
     __syncthreads();
     double* xbuf = reinterpret_cast<double*>(tw + G::TW_DIR) + (size_t)wave * G::XSLOTS;
     for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
-        const int32_t* src = reinterpret_cast<const int32_t*>(a.src) + (size_t)g * N;
         double re[R], im[R];
+        if (a.f64_io) {      // Spqlios_ifft (execute_reverse, fft_processor_spqlios.cpp:16-55): doubles in
+            const double* src = reinterpret_cast<const double*>(a.src) + (size_t)g * N;
 #pragma unroll
-        for (int m = 0; m < R; m++) { re[m] = (double)src[lane + 64 * m]; im[m] = (double)src[lane + 64 * m + P]; }
+            for (int m = 0; m < R; m++) { re[m] = src[lane + 64 * m]; im[m] = src[lane + 64 * m + P]; }
+        } else {
+            const int32_t* src = reinterpret_cast<const int32_t*>(a.src) + (size_t)g * N;
+#pragma unroll
+            for (int m = 0; m < R; m++) { re[m] = (double)src[lane + 64 * m]; im[m] = (double)src[lane + 64 * m + P]; }
+        }
         fft_forward<LOGN>(re, im, tw, xbuf, lane);
         if (a.dst_layout == 0) {
             double* dst = reinterpret_cast<double*>(a.dst) + (size_t)g * N;
@@ -413,6 +420,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fft_inverse(const FftArgs a) 
 #pragma unroll
         for (int m = 0; m < R; m++) { re[m] = src[G::pos3(lane, m)]; im[m] = src[P + G::pos3(lane, m)]; }
         fft_inverse<LOGN>(re, im, tw, tw, xbuf, lane);
+        if (a.f64_io) {      // Spqlios_fft (execute_direct, fft_processor_spqlios.cpp:108-153): doubles out, no truncation
+            double* dst = reinterpret_cast<double*>(a.dst) + (size_t)g * N;
+#pragma unroll
+            for (int m = 0; m < R; m++) { dst[lane + 64 * m] = re[m]; dst[lane + 64 * m + P] = im[m]; }
+            continue;
+        }
         uint32_t* dst = reinterpret_cast<uint32_t*>(a.dst) + (size_t)g * N;
 #pragma unroll
         for (int m = 0; m < R; m++) { dst[lane + 64 * m] = trunc_to_torus_wide(re[m]); dst[lane + 64 * m + P] = trunc_to_torus_wide(im[m]); }
@@ -438,6 +451,51 @@ __global__ void k_bk_permute(const double* __restrict__ src, double* __restrict_
             dst[g * N + pos] = src[gd * N + 2 * k];
             dst[g * N + P + pos] = src[gd * N + 2 * k + 1];
         }
+    }
+}
+
+// Spqlios_poly_mul (spqlios-wrapper.cpp:38-53): res = a (*) b mod X^N + 1 through the transform: both operands viewed as signed
+// i32, forward transforms, complex pointwise product (aimbim = ai bi; arebim = ar bi; re = ar br - aimbim; im = ai br + arebim),
+// inverse transform with truncation.  Every product and sum rounded on its own (the reference builds this loop with -Ofast and
+// may contract it: off the gate path, parity there is +-1 LSB).
+struct PolyMulArgs {
+    const cplx* tw;
+    const uint32_t* a;    // [count][N]
+    const uint32_t* b;    // [count][N]
+    uint32_t* res;        // [count][N]
+    int32_t count;
+};
+template <int LOGN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_poly_mul(const PolyMulArgs a) {
+    typedef Geo<LOGN> G;
+    constexpr int N = G::N, P = G::P, R = G::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < G::TW_TOTAL; idx += 64 * WAVES) tw[idx] = a.tw[idx];
+    __syncthreads();
+    double* xbuf = reinterpret_cast<double*>(tw + G::TW_TOTAL) + (size_t)wave * G::XSLOTS;
+    for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
+        const int32_t* pa = reinterpret_cast<const int32_t*>(a.a) + (size_t)g * N;
+        const int32_t* pb = reinterpret_cast<const int32_t*>(a.b) + (size_t)g * N;
+        double ar[R], ai[R], br[R], bi[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { ar[m] = (double)pa[lane + 64 * m]; ai[m] = (double)pa[lane + 64 * m + P]; }
+        fft_forward<LOGN>(ar, ai, tw, xbuf, lane);
+#pragma unroll
+        for (int m = 0; m < R; m++) { br[m] = (double)pb[lane + 64 * m]; bi[m] = (double)pb[lane + 64 * m + P]; }
+        fft_forward<LOGN>(br, bi, tw, xbuf, lane);
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const double aimbim = ai[m] * bi[m], arebim = ar[m] * bi[m];
+            const double t0 = ar[m] * br[m], t1 = ai[m] * br[m];
+            ar[m] = t0 - aimbim;
+            ai[m] = t1 + arebim;
+        }
+        fft_inverse<LOGN>(ar, ai, tw + G::TW_DIR, tw + G::TW_DIR, xbuf, lane);
+        uint32_t* dst = a.res + (size_t)g * N;
+#pragma unroll
+        for (int m = 0; m < R; m++) { dst[lane + 64 * m] = trunc_to_torus_wide(ar[m]); dst[lane + 64 * m + P] = trunc_to_torus_wide(ai[m]); }
     }
 }
 

@@ -200,6 +200,28 @@ class Engine:
         self._ck(self.L.rtfhe_ifft_i32_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
         return res
 
+    def ifft_f64_batch(self, src):
+        """Spqlios_ifft: forward transform of double polynomials."""
+        src = _np(src, np.float64).reshape(-1, self.p.N)
+        res = np.empty(src.shape, np.float64)
+        self._ck(self.L.rtfhe_ifft_f64_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
+        return res
+
+    def fft_f64_batch(self, src):
+        """Spqlios_fft: inverse transform to doubles (scaled by 2/N, no truncation)."""
+        src = _np(src, np.float64).reshape(-1, self.p.N)
+        res = np.empty(src.shape, np.float64)
+        self._ck(self.L.rtfhe_fft_f64_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
+        return res
+
+    def poly_mul_batch(self, a, b):
+        """Spqlios_poly_mul: negacyclic product of torus polynomials through the FP64 transform."""
+        a = _np(a, np.uint32).reshape(-1, self.p.N)
+        b = _np(b, np.uint32).reshape(a.shape)
+        res = np.empty_like(a)
+        self._ck(self.L.rtfhe_poly_mul_batch(self.h, _ptr(a), _ptr(b), _ptr(res), a.shape[0]))
+        return res
+
     def fft_u32_batch(self, src):
         src = _np(src, np.float64).reshape(-1, self.p.N)
         res = np.empty(src.shape, np.uint32)

@@ -148,7 +148,7 @@ def test_config1_example_and_sharded_path_on_one_gpu(engine, params, keys):
 
 
 def test_dispatch_boundaries_are_seamless(engine, params, keys):
-    """Batch sizes around every launch-shape boundary (512 | 1024 gates on 256 CUs) and odd sizes: gate g's output must
+    """Batch sizes around every launch-shape boundary (1, 2, 3, 4 gates per CU on 256 CUs: 256 | 512 | 768 | 1024 gates, alone and as the remainder of a larger batch) and odd sizes: gate g's output must
     not depend on the batch it travels in."""
     import rustfhe_amd as R
     rng = np.random.default_rng(123)
@@ -157,7 +157,7 @@ def test_dispatch_boundaries_are_seamless(engine, params, keys):
     c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
     full = engine.gate_batch(R.NAND, c0, c1)
     assert keys.decrypt_bits(full) == list(1 - (b0 & b1))
-    for k in (1, 2, 7, 63, 65, 255, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2049):
+    for k in (1, 2, 7, 63, 65, 255, 256, 257, 300, 511, 512, 513, 700, 767, 768, 769, 1023, 1024, 1025, 1281, 1537, 1793, 2047, 2049):
         part = engine.gate_batch(R.NAND, c0[:k], c1[:k])
         assert np.array_equal(part, full[:k]), k
     # a long run of launches leaves results unchanged (no state carried between calls)

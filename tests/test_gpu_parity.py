@@ -293,3 +293,25 @@ def test_dev_entry_points_refuse_host_pointers(engine, params, keys):
     engine.gate_batch_dev(R.NAND, int(pin.ctypes.data), d, out, 3)
     engine.sync()
     assert keys.decrypt_bits(out.cpu().numpy().view(np.uint32)) == [0, 1, 0]
+
+
+def test_rest_of_the_reference_fft_ffi(engine, orc, params):
+    """Spqlios_ifft / Spqlios_fft on doubles and Spqlios_poly_mul (spqlios-wrapper.cpp:18-20, 30-32, 38-53; off the gate path):
+    bit-exact against the oracle's restatement; the reference KAT of poly_mul's meaning (X + X^2)^2 = X^2 + 2 X^3 + X^4
+    (utils/src/spqlios.rs:243-276, there at N = 16) holds at N = 1024 too."""
+    rng = np.random.default_rng(31)
+    pl = orc.Plan(params.N)
+    src = rng.standard_normal((5, params.N)) * 2.0 ** rng.integers(0, 40, (5, 1))
+    assert engine.ifft_f64_batch(src).tobytes() == np.stack([pl.ifft_f64(s) for s in src]).tobytes()
+    spec = np.stack([pl.ifft_i32(rng.integers(-2 ** 31, 2 ** 31, params.N).astype(np.int32)) for _ in range(5)])
+    assert engine.fft_f64_batch(spec).tobytes() == np.stack([pl.fft_f64(s) for s in spec]).tobytes()
+    a = rng.integers(0, 2 ** 32, (6, params.N), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(-64, 64, (6, params.N)).astype(np.int32).view(np.uint32)          # small multiplier: the product stays exact-ish
+    got = engine.poly_mul_batch(a, b)
+    assert np.array_equal(got, np.stack([pl.poly_mul(x, y) for x, y in zip(a, b)]))
+    p = np.zeros((1, params.N), np.uint32)
+    p[0, 1] = p[0, 2] = 1
+    sq = engine.poly_mul_batch(p, p)[0]
+    want = np.zeros(params.N, np.uint32)
+    want[2], want[3], want[4] = 1, 2, 1
+    assert np.array_equal(sq, want)
