@@ -442,8 +442,8 @@ int launch_bootstrap_ntt_w(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     return 0;
 }
 
-int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
-    constexpr int GATES = 4;
+template <int GATES>
+int launch_bootstrap_ntt_pair_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     auto k = k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, GATES>;
     const size_t lds = NttPairLds::bytes(GATES, b.npad);
     if (int rc = allow_lds(ctx, k, lds)) return rc;
@@ -452,6 +452,23 @@ int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     HIPCHECK(ctx, hipGetLastError());
     ctx->launches++;
     return 0;
+}
+
+// NTT backend, two waves per gate.  Whole rounds of 4 gates per CU in one launch; a remainder runs with 1 / 2 / 3 gates per
+// workgroup (one workgroup per CU): with fewer gates per CU a gate's two waves share their SIMDs with fewer other waves -- a
+// circuit wave of 1-3 gates takes 0.67 x the time of a full round instead of all of it.
+int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * ntt::N : (size_t)a.n + 1;
+    const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
+    const size_t full = count / round * round, rem = count - full;
+    if (full)
+        if (int rc = launch_bootstrap_ntt_pair_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+    if (!rem) return 0;
+    const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+    if (rem <= cus) return launch_bootstrap_ntt_pair_g<1>(ctx, tail, s);
+    if (rem <= 2 * cus) return launch_bootstrap_ntt_pair_g<2>(ctx, tail, s);
+    if (rem <= 3 * cus) return launch_bootstrap_ntt_pair_g<3>(ctx, tail, s);
+    return launch_bootstrap_ntt_pair_g<4>(ctx, tail, s);
 }
 
 int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_in0, const void* d_in1, void* d_out,
@@ -596,6 +613,9 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<10>(4, npad, bootstrap_dual_xbuf(10, 4)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 8>, bootstrap_lds_bytes<10>(8, npad, bootstrap_dual_xbuf(10, 8)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 4>, NttPairLds::bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 3>, NttPairLds::bytes(3, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 2>, NttPairLds::bytes(2, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 1>, NttPairLds::bytes(1, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt<3, 6, 8, 2, KSQ, 4>, ntt_lds_bytes(4, npad))) return rc;
     } else {
         if (int rc = allow_lds(ctx, k_bootstrap<11, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<11>(4, npad, bootstrap_dual_xbuf(11, 4)))) return rc;

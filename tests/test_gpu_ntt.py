@@ -67,6 +67,9 @@ def test_ntt_batch_decrypts_and_all_shapes_agree(ntt_engine, engine, params, key
     out = ntt_engine.gate_batch(R.NAND, c0, c1)
     assert keys.decrypt_bits(out) == list(1 - (b0 & b1))
     assert np.array_equal(ntt_engine.gate_batch(R.NAND, c0[:5], c1[:5]), out[:5])
+    # launch shapes by batch size (1, 2, 3, 4 gates per workgroup for the remainder of a batch): the same words in every shape
+    for k in (256, 257, 512, 513, 768, 769, 1024, 1025, 1300):
+        assert np.array_equal(ntt_engine.gate_batch(R.NAND, c0[:k], c1[:k]), out[:k]), k
     for op, f in ((R.XOR, lambda x, y: x ^ y), (R.OR, lambda x, y: x | y)):
         o = ntt_engine.gate_batch(op, c0[:64], c1[:64])
         assert keys.decrypt_bits(o) == list(f(b0[:64], b1[:64]))
