@@ -142,11 +142,25 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
     // polynomial are requested once its decomposition words are dead (after the first stage), the others as a buffer retires
     const size_t trgsw_cplx = (size_t)2 * L * 2 * 2 * R * 64;
     cplx bA[R], bB[R];
+    // read through a buffer resource: scalar row offset + one per-lane VGPR + immediates (see k_bootstrap_pair)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(ha.hbk), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane0 * 16;
     auto fetch = [&](cplx (&dst)[R], int step, int rc) {
-        const cplx* src = ha.hbk + (size_t)step * trgsw_cplx + (size_t)((rc >> 1) * 2 + (rc & 1)) * 2 * R * 64 + (size_t)H * R * 64 + lane0;
+        const size_t row = (size_t)step * trgsw_cplx + (size_t)((rc >> 1) * 2 + (rc & 1)) * 2 * R * 64 + (size_t)H * R * 64;
+        const int s_lo = __builtin_amdgcn_readfirstlane((int)(row * sizeof(cplx)));
+        const int s_hi = s_lo + (R / 2) * 64 * (int)sizeof(cplx);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < R; m++) dst[m] = src[m * 64];
+        for (int m = 0; m < R / 2; m++) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_lo, 0);
+            dst[m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+        }
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_hi, 0);
+            dst[R / 2 + m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     if (H) __builtin_amdgcn_s_setprio(HALVES_PRIO_B);

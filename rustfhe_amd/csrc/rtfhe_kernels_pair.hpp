@@ -144,15 +144,31 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     // runs across steps: each is refilled right after its multiply-accumulate retires, two MACs ahead of its use, the
     // last two refills of a step fetching rows 0, 1 of the next one.
     cplx bA[R], bB[R];
+    // Key rows are read through a buffer resource over the whole key: address = descriptor base + scalar row offset + lane * 16 +
+    // immediate.  The row offset lives in SGPRs (SALU arithmetic), the per-lane part is one VGPR for the whole kernel: no
+    // 64-bit vector address arithmetic per load (global_load with a vector address cost ~50 VALU instructions per step).
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(a.bk), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
     auto fetch = [&](cplx (&dst)[R], int step, int rc) {
 #ifdef ABL_BKHOT      // timing ablation only (wrong results): every key row load hits the same (cache-resident) row
-        const cplx* src = a.bk + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + lane + 0 * step;
+        const size_t row = (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + 0 * step;
 #else
-        const cplx* src = a.bk + (size_t)step * trgsw_cplx + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + lane;
+        const size_t row = (size_t)step * trgsw_cplx + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64;
 #endif
+        const int s_lo = __builtin_amdgcn_readfirstlane((int)(row * sizeof(cplx)));
+        const int s_hi = s_lo + (R / 2) * 64 * (int)sizeof(cplx);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < R; m++) dst[m] = src[m * 64];
+        for (int m = 0; m < R / 2; m++) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_lo, 0);
+            dst[m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+        }
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_hi, 0);
+            dst[R / 2 + m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     if (a.steps > 0) {   // side 0 starts its ring with (bB, bA), side 1 with (bA, bB)
