@@ -318,8 +318,8 @@ int launch_bootstrap_pair10_g(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
 int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return launch_bootstrap_pair10_g<4>(ctx, a, s); }
 
 // N = 2048: two waves per transform (rtfhe_kernels_halves.hpp)
-int launch_bootstrap_halves11(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
-    constexpr int GATES = 4;
+template <int GATES>
+int launch_bootstrap_halves11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     auto k = k_bootstrap_halves<3, 6, 8, 2, KSQ, GATES>;
     const size_t lds = HalvesLds::bytes(GATES, b.npad);
     if (int rc = allow_lds(ctx, k, lds)) return rc;
@@ -370,8 +370,20 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     } else {
         // two waves per transform (two waves per SIMD, no AGPR traffic); RTFHE_FORCE_WAVES=4 selects one wave per gate
         // (inverse pass-1/untwist twiddles in global memory: 4 gates per CU fit)
-        if (ctx->d_htw && ctx->d_hbk && ctx->force_waves != 4) return launch_bootstrap_halves11(ctx, a, s);
-        return launch_bootstrap_w<11, 4>(ctx, a, s);
+        if (!(ctx->d_htw && ctx->d_hbk) || ctx->force_waves == 4) return launch_bootstrap_w<11, 4>(ctx, a, s);
+        // whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU
+        // (a gate's two waves then share their SIMDs with fewer other waves: a single gate takes 0.67 x a full round)
+        const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * (1 << LOGN) : (size_t)a.n + 1;
+        const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
+        const size_t full = count / round * round, rem = count - full;
+        if (full)
+            if (int rc = launch_bootstrap_halves11_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (!rem) return 0;
+        const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+        if (rem <= cus) return launch_bootstrap_halves11_g<1>(ctx, tail, s);
+        if (rem <= 2 * cus) return launch_bootstrap_halves11_g<2>(ctx, tail, s);
+        if (rem <= 3 * cus) return launch_bootstrap_halves11_g<3>(ctx, tail, s);
+        return launch_bootstrap_halves11_g<4>(ctx, tail, s);
     }
 }
 
@@ -620,6 +632,9 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
     } else {
         if (int rc = allow_lds(ctx, k_bootstrap<11, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<11>(4, npad, bootstrap_dual_xbuf(11, 4)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 4>, HalvesLds::bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 3>, HalvesLds::bytes(3, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 2>, HalvesLds::bytes(2, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 1>, HalvesLds::bytes(1, npad))) return rc;
     }
     return 0;
 }

@@ -249,5 +249,11 @@ def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch):
         for steps in (0, 1, 2, 9):
             assert np.array_equal(e.blind_rotate_batch(t, steps), one.blind_rotate_batch(t, steps))
         assert K.decrypt_bits(e.gate_batch(R.NAND, c0, c1)) == list(1 - (b0 & b1))
+        # launch shapes by batch size (1, 2, 3 gates per workgroup below a full round): the same words as one wave per gate
+        bb0, bb1 = rng.integers(0, 2, 600), rng.integers(0, 2, 600)
+        d0, d1 = K.encrypt_bits(bb0), K.encrypt_bits(bb1)
+        ref = one.gate_batch(R.NAND, d0, d1)
+        for k in (257, 600):
+            assert np.array_equal(e.gate_batch(R.NAND, d0[:k], d1[:k]), ref[:k]), k
     finally:
         one.close()
