@@ -142,7 +142,8 @@ int rtfhe_circuit_wave_dev(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0
 /* A whole levelised netlist as ONE submission (BASELINE config 4; the reference walks its expression tree gate by gate,
  * nander/src/lib.rs:72-89): the waves wave_offsets[w] .. wave_offsets[w+1] (host array, num_waves + 1 entries) of the same four
  * device arrays are captured once into a HIP graph; rtfhe_circuit_launch replays it on `stream` (asynchronous, one runtime
- * call per evaluation).  The device arrays and the wire table must stay alive and in place while the circuit exists. */
+ * call per evaluation).  The device arrays and the wire table must stay alive and in place while the circuit exists, and a circuit
+ * must be destroyed before the context it was created on. */
 typedef struct rtfhe_circuit rtfhe_circuit;
 int rtfhe_circuit_create(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0, const void *d_idx1, const void *d_idx_out,
                          const int32_t *wave_offsets, int32_t num_waves, void *d_wires, size_t num_wires, rtfhe_circuit **out);

@@ -99,8 +99,11 @@ bool os_random(void* buf, size_t len) {
 // where the per-row generators come from: a seed (test only) or a ChaCha key from the OS
 struct Source {
     bool secure = false; uint64_t seed = 0; uint32_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ~Source() { volatile uint32_t* p = key; for (int i = 0; i < 8; i++) p[i] = 0; }      // the ChaCha key does not outlive the call
     static bool from_os(Source& s) { s.secure = true; return os_random(s.key, sizeof(s.key)); }
     static Source from_seed(uint64_t seed) { Source s; s.seed = seed; return s; }
+    Source() = default;
+    Source(const Source&) = default;
 };
 
 uint32_t torus_from_f32(float v) {
