@@ -1,0 +1,323 @@
+// rtfhe_kernels_ntt_halves.hpp -- the exact-integer NTT backend at N = 2048 (BASELINE config 5 on the backend north_star names).
+//
+// Same prime (P = 2^50 - 16383: 2^14 | P - 1, so the 4096-th roots of unity the negacyclic transform of 2048 points needs exist)
+// and the same 1024-point wave transforms as N = 1024 (rtfhe_ntt.hpp), arranged as k_bootstrap_halves arranges the FFT mirror:
+// the two waves of a gate split every transform by its top index bit.
+//   forward : the first Cooley-Tukey stage (stride 1024, one twiddle zeta_1 = psi^1024) pairs coefficient j with j + 1024:
+//             wave 0 keeps x0 + zeta_1 x1, wave 1 keeps x0 - zeta_1 x1 (both gather and decompose all 2048 coefficients: no
+//             synchronisation inside a forward transform), then each runs the 1024-point transform of its half, whose block
+//             twiddles are those of the 2048-point table: zeta_{k' + (1 + H) 2^floor(log2 k')} for the sub-transform's index k'
+//   products: each wave owns its half of the points for all six rows and both components
+//   inverse : the 1024-point Gentleman-Sande transform per half, then the last stage (stride 1024) across the halves: the waves
+//             swap their results through their exchange buffers (two LDS-only barriers); wave 0 keeps u + v = coefficients
+//             [0, 1024), wave 1 zeta_1^-1 (u - v) = coefficients [1024, 2048)
+//   sums    : a gate's sum of 2l = 6 products reaches 2^49.58 > P/2 at N = 2048, a sum of 3 stays below 2^48.58: the three b-rows
+//             and the three a-rows are accumulated and inverse-transformed SEPARATELY and added as torus words (four inverse
+//             transforms per step instead of two)
+// scripts/ntt/model2048.py runs this construction on exact integers (equal to the schoolbook negacyclic product on random and
+// extreme inputs, every intermediate below 2^53).  Outputs are bit-identical to the oracle's exact_int backend.
+//
+// LDS: 16 KiB of accumulator per gate; passes 1 and 2 of the four tables (two halves x two directions) in LDS, the per-lane
+// pass-3 entries (6 KiB per table) are read from global memory.
+#pragma once
+
+#include "rtfhe_kernels_ntt.hpp"
+
+namespace rtfhe {
+
+struct NttHalvesTw {
+    // global table, doubles: [half][direction][ntt::TW_DIR_PAD]; the pad entry (index ntt::TW_DIR) holds the twiddle of the stage
+    // across the halves: zeta_1 (forward) / zeta_1^-1 (inverse)
+    static constexpr int CROSS = ntt::TW_DIR;
+    static constexpr int TABLE = ntt::TW_DIR_PAD;
+    static constexpr int GLOBAL_TOTAL = 4 * TABLE;
+    // LDS copy: [half][direction][SMALL]: passes 1 and 2 (entries 0 .. TW_P3 - 1) and the cross twiddle at TW_P3
+    static constexpr int SMALL = 256;
+    static_assert(ntt::TW_P3 == SMALL - 1, "passes 1 and 2 + one entry");
+    static constexpr int LDS_TOTAL = 4 * SMALL;
+};
+
+struct NttHalvesLds {
+    static constexpr size_t TW = (size_t)NttHalvesTw::LDS_TOTAL * sizeof(double);
+    static constexpr size_t XB = (size_t)ntt::XSLOTS * sizeof(double);
+    static_assert(ntt::XSLOTS >= ntt::N, "an exchange buffer must hold one half");
+    __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB; }
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
+};
+
+// key in the NTT domain, N = 2048: double[n][2l rows][2 comp][2 half][8][64 lanes][2]; N^-1 folded in; centred residues
+__device__ __forceinline__ const double2* ntt_halves_bk_row(const double* bk_i, int row, int comp, int H, int lane) {
+    return reinterpret_cast<const double2*>(bk_i + ((size_t)((row * 2 + comp) * 2 + H) * ntt::N)) + lane;
+}
+
+// the tables of one wave: tws = LDS copy of its half ([direction][SMALL]), twg = global table of its half ([direction][TABLE])
+struct NttHalvesTables {
+    const double* fwd_s;
+    const double* inv_s;
+    const double* fwd_g;
+    const double* inv_g;
+    __device__ __forceinline__ NttHalvesTables(const double* lds, const double* glob, int H)
+        : fwd_s(lds + (size_t)(2 * H) * NttHalvesTw::SMALL), inv_s(lds + (size_t)(2 * H + 1) * NttHalvesTw::SMALL),
+          fwd_g(glob + (size_t)(2 * H) * NttHalvesTw::TABLE), inv_g(glob + (size_t)(2 * H + 1) * NttHalvesTw::TABLE) {}
+};
+
+__device__ __forceinline__ void ntt_halves_load_tables(double* lds, const double* glob, int tid, int nthreads) {
+    for (int idx = tid; idx < NttHalvesTw::LDS_TOTAL; idx += nthreads) {
+        const int t = idx / NttHalvesTw::SMALL, e = idx % NttHalvesTw::SMALL;
+        lds[idx] = glob[t * NttHalvesTw::TABLE + (e < ntt::TW_P3 ? e : NttHalvesTw::CROSS)];
+    }
+}
+
+// One external product (CMUX = false: acc <- BK_i (x) acc) or one CMUX step (acc += BK_i (x) ((X^r - 1) acc)) by the two waves of a
+// gate.  Every wave of the workgroup must call it (workgroup barriers inside).
+template <int L, int BGBIT, bool CMUX>
+__device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const double* __restrict__ bk_i,
+                                                const NttHalvesTables& t, double* __restrict__ myx, const double* __restrict__ otx,
+                                                int lane0, int H) {
+    constexpr int LOGN = 11, N = 2048, HN = 1024, R = ntt::R;
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    uint32_t u0[R], u1[R];
+    auto gather = [&](const uint32_t* poly, int lane) {
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane + 64 * m;
+            const uint32_t d0 = CMUX ? (rotated_coef<LOGN>(poly, c, r) - poly[c]) : poly[c];
+            const uint32_t d1 = CMUX ? (rotated_coef<LOGN>(poly, c + HN, r) - poly[c + HN]) : poly[c + HN];
+            u0[m] = (d0 + M) ^ M;
+            u1[m] = (d1 + M) ^ M;
+        }
+    };
+    gather(accbuf, lane0);
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));      // addresses are re-derived per polynomial instead of living across the step
+        double s0[R], s1[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { s0[m] = 0.0; s1[m] = 0.0; }
+        const double zc = t.fwd_s[ntt::TW_P3];
+#pragma unroll 1
+        for (int jj = 0; jj < L; jj++) {
+            double x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const double d0 = (double)decomp_digit(u0[m], BGBIT, jj), d1 = (double)decomp_digit(u1[m], BGBIT, jj);
+                const double tt = ntt::modmul(d1, zc);         // |d1| <= Bg/2: the quotient is exact, |tt| <= P/2
+                x[m] = H ? d0 - tt : d0 + tt;
+            }
+            const double2* b0p = ntt_halves_bk_row(bk_i, h * L + jj, 0, H, lane);
+            const double2* b1p = ntt_halves_bk_row(bk_i, h * L + jj, 1, H, lane);
+            double2 b0[R / 2], b1[R / 2];
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
+            ntt::forward_a(x, t.fwd_s, myx, lane);
+            ntt::forward_b(x, t.fwd_g, myx, lane);
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) {
+                s0[2 * q] += ntt::modmul(x[2 * q], b0[q].x);     s0[2 * q + 1] += ntt::modmul(x[2 * q + 1], b0[q].y);
+                s1[2 * q] += ntt::modmul(x[2 * q], b1[q].x);     s1[2 * q + 1] += ntt::modmul(x[2 * q + 1], b1[q].y);
+            }
+        }
+        // the a-polynomial's words leave the accumulator before the b-rows' results go into it (the partner's gather is ordered
+        // before its own next barrier in the same way)
+        if (h == 0) gather(accbuf + N, lane);
+        const double zi = t.inv_s[ntt::TW_P3];
+#pragma unroll 1
+        for (int comp = 0; comp < 2; comp++) {
+            double x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) x[m] = comp ? s1[m] : s0[m];
+            ntt::inverse(x, t.inv_s, t.inv_g, myx, lane);
+            // x[m] = sub-coefficient lane + 64 m of this half (u on wave 0, v on wave 1), |x| <= P/2
+#pragma unroll
+            for (int m = 0; m < R; m++) myx[lane + 64 * m] = x[m];
+            lds_barrier();
+            uint32_t* poly = accbuf + comp * N + H * HN;
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const double o = otx[lane + 64 * m];
+                const double v = H ? ntt::normalize(ntt::modmul(o - x[m], zi)) : ntt::normalize(x[m] + o);
+                const uint32_t w = ntt::to_torus(v);
+                if (CMUX || h == 1) poly[lane + 64 * m] += w;
+                else poly[lane + 64 * m] = w;
+            }
+            lds_barrier();      // the partner has read my buffer; both halves of the polynomial are written
+        }
+    }
+}
+
+struct NttHalvesArgs {
+    BootstrapArgs b;          // tw and bk of `b` are unused here
+    const double* ntt_tw;     // [NttHalvesTw::GLOBAL_TOTAL]
+    const double* ntt_bk;     // layout above
+};
+
+template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
+__global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const NttHalvesArgs args) {
+    constexpr int LOGN = 11, N = 2048, R = ntt::R, NT = 128 * GATES;
+    const BootstrapArgs& a = args.b;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave % GATES, H = wave / GATES;          // the two halves of a gate share a SIMD (waves w, w + GATES)
+    ntt_halves_load_tables(tw, args.ntt_tw, tid, NT);
+    const NttHalvesTables tables(tw, args.ntt_tw, H);
+
+    const int g_raw = blockIdx.x * GATES + slot;
+    const int g = g_raw < a.count ? g_raw : a.count - 1;
+    const GateIo io = gate_io(a, g);
+    const bool live = g_raw < a.count && io.ok;      // idle / skipped gates still take part in every barrier
+
+    unsigned char* gbase = smem + NttHalvesLds::TW + (size_t)slot * NttHalvesLds::gate_bytes(a.npad);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
+    uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
+    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + NttHalvesLds::abar_bytes(a.npad));
+    double* xb1 = xb0 + ntt::XSLOTS;
+    double* myx = H ? xb1 : xb0;
+    const double* otx = H ? xb0 : xb1;
+
+    const int n = a.n;
+    {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane0 + 64 * H; i <= n; i += 128) {
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
+            abar[i] = (uint16_t)((i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH));
+        }
+    }
+    __syncthreads();
+    {   // acc = X^{-bbar} * testvec (tfhe.rs:85, 98-106); each wave initialises half of the words
+        const int bbar = (int)abar[n];
+        for (int c = lane0 + 64 * H; c < 2 * N; c += 128) {
+            const int e = (c + bbar) & (2 * N - 1);
+            accbuf[c] = c < N ? ((e >> LOGN) ? 0xE0000000u : 0x20000000u) : 0u;
+        }
+    }
+    __syncthreads();
+
+    const size_t trgsw_doubles = (size_t)2 * L * 2 * N;
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        ntt_halves_step<L, BGBIT, true>(accbuf, r, args.ntt_bk + (size_t)i * trgsw_doubles, tables, myx, otx, lane0, H);
+    }
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        if (live) {
+            uint32_t* o = a.out + (size_t)g * 2 * N;
+            for (int c = lane0 + 64 * H; c < 2 * N; c += 128) o[c] = accbuf[c];
+        }
+        return;
+    }
+    // sample extract index 0 (trlwe.rs:110-121): a'_0 = a_0, a'_k = -a_{N-k}; b' = b_0
+    {
+        uint32_t av[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) av[m] = accbuf[N + lane0 + 64 * m + 1024 * H];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = lane0 + 64 * m + 1024 * H;
+            accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[m] : (0u - av[m]);
+        }
+    }
+    __syncthreads();
+    // identity key switch (tlwe.rs:43-73): each wave sums the rows of half of the coefficients
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, H * (N / 2), (H + 1) * (N / 2), a.ksk, a.ksw, sum, lane0);
+    uint4* part = reinterpret_cast<uint4*>(xb1) + lane0;   // [KSQ][64] uint4
+    if (H == 1) {
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) part[q * 64] = sum[q];
+    }
+    __syncthreads();
+    if (H == 0 && live) {
+        const uint32_t bprime = accbuf[0];
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) {
+            const uint4 o = part[q * 64];
+            const int col = 4 * (lane0 + 64 * q);
+            const uint32_t s[4] = {sum[q].x + o.x, sum[q].y + o.y, sum[q].z + o.z, sum[q].w + o.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (col + e <= n) io.out[col + e] = ((col + e == n) ? bprime : 0u) - s[e];
+        }
+    }
+}
+
+struct NttHalvesBkArgs {
+    const double* ntt_tw;       // [NttHalvesTw::GLOBAL_TOTAL]
+    const uint32_t* bk_torus;   // [n][2][2l][N]
+    double* ntt_bk;
+    int32_t count;              // polynomials
+    int32_t rows;               // 2l
+    double ninv;                // N^-1 mod P, centred
+};
+
+// key rows -> NTT domain at N = 2048 (the counterpart of TRGSWRepF::from, hom_nand/src/trgsw.rs:68-76): one wave per polynomial,
+// both halves one after the other
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_ntt_bk_halves(const NttHalvesBkArgs a) {
+    constexpr int N = 2048, HN = 1024, R = ntt::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);                   // forward tables of both halves, whole
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < 2 * NttHalvesTw::TABLE; idx += 64 * WAVES)
+        tw[idx] = a.ntt_tw[(size_t)(2 * (idx / NttHalvesTw::TABLE)) * NttHalvesTw::TABLE + idx % NttHalvesTw::TABLE];
+    __syncthreads();
+    double* xbuf = tw + 2 * NttHalvesTw::TABLE + (size_t)wave * ntt::XSLOTS;
+    const double zc = tw[NttHalvesTw::CROSS];
+    for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
+        const int32_t* src = reinterpret_cast<const int32_t*>(a.bk_torus) + (size_t)g * N;
+        double* dst_poly = a.ntt_bk + bk_poly_remap((size_t)g, a.rows) * N;
+#pragma unroll 1
+        for (int H = 0; H < 2; H++) {
+            double x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const double x0 = (double)src[lane + 64 * m];
+                const double tt = ntt::normalize(ntt::modmul((double)src[HN + lane + 64 * m], zc));
+                x[m] = H ? x0 - tt : x0 + tt;
+            }
+            ntt::forward(x, tw + (size_t)H * NttHalvesTw::TABLE, xbuf, lane);
+            double2* dst = reinterpret_cast<double2*>(dst_poly + (size_t)H * HN) + lane;
+#pragma unroll
+            for (int q = 0; q < R / 2; q++)
+                dst[q * 64] = make_double2(ntt::normalize(ntt::modmul(x[2 * q], a.ninv)), ntt::normalize(ntt::modmul(x[2 * q + 1], a.ninv)));
+        }
+    }
+}
+
+struct NttHalvesExtProdArgs {
+    const double* ntt_tw;
+    const double* ntt_bk;
+    const int32_t* bk_index;
+    const uint32_t* trlwe;
+    uint32_t* out;
+    int32_t count;
+};
+
+// stage-level external product (test surface): one gate per workgroup of two waves
+template <int L, int BGBIT>
+__global__ __launch_bounds__(128, 1) void k_external_product_ntt_halves(const NttHalvesExtProdArgs a) {
+    constexpr int N = 2048;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tw = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int H = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ntt_halves_load_tables(tw, a.ntt_tw, tid, 128);
+    const NttHalvesTables tables(tw, a.ntt_tw, H);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(smem + NttHalvesLds::TW);
+    double* xb0 = reinterpret_cast<double*>(smem + NttHalvesLds::TW + (size_t)2 * N * 4);
+    double* xb1 = xb0 + ntt::XSLOTS;
+    const int g = blockIdx.x;                       // grid = count
+    for (int c = tid; c < 2 * N; c += 128) accbuf[c] = a.trlwe[(size_t)g * 2 * N + c];
+    __syncthreads();
+    ntt_halves_step<L, BGBIT, false>(accbuf, 0, a.ntt_bk + (size_t)a.bk_index[g] * ((size_t)2 * L * 2 * N), tables,
+                                     H ? xb1 : xb0, H ? xb0 : xb1, lane, H);
+    __syncthreads();
+    for (int c = tid; c < 2 * N; c += 128) a.out[(size_t)g * 2 * N + c] = accbuf[c];
+}
+
+}  // namespace rtfhe

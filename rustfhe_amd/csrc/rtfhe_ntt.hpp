@@ -137,10 +137,12 @@ __device__ __forceinline__ void forward(double (&x)[R], const double* __restrict
 }
 
 // in: layout L3, |x| < 2^52.  out: layout L1, the centred residue (= the exact integer when |true value| < P/2).
-__device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+// tw3: the table the per-lane pass-3 entries are read from (the N = 2048 kernel keeps that part in global memory).
+__device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict__ tw, const double* __restrict__ tw3,
+                                        double* __restrict__ xbuf, int lane) {
     double z1[15], z2[15], z3[12];
 #pragma unroll
-    for (int e = 0; e < 12; e++) z3[e] = tw[TW_P3 + e * 64 + lane];
+    for (int e = 0; e < 12; e++) z3[e] = tw3[TW_P3 + e * 64 + lane];
     normalize_all(x);
 #pragma unroll
     for (int m = 0; m < R; m += 2) {
@@ -169,6 +171,10 @@ __device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict
     normalize_all(x);
     inv_stage<3>(x, z1);
     normalize_all(x);
+}
+
+__device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
+    inverse(x, tw, tw, xbuf, lane);
 }
 
 // exact integer (|x| < 2^51) -> torus word: the low 32 bits of the two's-complement value

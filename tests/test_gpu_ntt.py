@@ -119,3 +119,91 @@ def test_ntt_two_waves_per_gate_kernel_gives_the_same_words(ntt_engine, params, 
         assert np.array_equal(e.blind_rotate_batch(in0[:5], 9), ntt_engine.blind_rotate_batch(in0[:5], 9))
     finally:
         e.close()
+
+
+# ---- N = 2048 (BASELINE config 5) on the NTT backend: k_bootstrap_ntt_halves, two waves per transform ----
+@pytest.fixture(scope="module")
+def ntt2048(orc):
+    import rustfhe_amd as R
+    P = orc.Params(N=2048)
+    K = orc.Keys(P, 2048)
+    e = R.Engine(R.Params(N=2048), 0)
+    e.load_bk_torus(K.bk_t)
+    e.load_ksk(K.ksk)
+    e.set_backend(R._ffi.BACKEND_NTT_EXACT)
+    yield P, K, e
+    e.close()
+
+
+def test_ntt2048_external_product_is_exact(ntt2048, orc):
+    P, K, e = ntt2048
+    rng = np.random.default_rng(2049)
+    idx = np.array([0, 5, 634, 300, 17], np.int32)
+    trlwe = rng.integers(0, 2 ** 32, (5, 2 * P.N), dtype=np.uint64).astype(np.uint32)
+    trlwe[1] = 0
+    trlwe[2] = 0xFFFFFFFF
+    trlwe[3] = 0x7DF7C000          # every digit at the top of its range: the row sums at their largest
+    out = e.external_product_batch(idx, trlwe)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    w = P.trgsw_words
+    exp = np.stack([orc.external_product(P, pl, None, K.bk_t[i * w:(i + 1) * w], t) for i, t in zip(idx, trlwe)])
+    assert np.array_equal(out.reshape(exp.shape), exp)
+
+
+def test_ntt2048_largest_sums_stay_exact(orc):
+    """A key of extreme words against extreme digits: each of the two 3-row sums reaches 3 * 2048 * 32 * 2^31 = 2^48.58 < P/2; the sum
+    of all six rows (2^49.58) would not fit -- the reason the kernel inverse-transforms the b-rows and the a-rows separately."""
+    import rustfhe_amd as R
+    P = orc.Params(n=2, N=2048)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    w = P.trgsw_words
+    bk = np.empty(2 * w, np.uint32)
+    bk[:w] = 0x80000000            # -2^31 everywhere
+    bk[w:] = 0x7FFFFFFF
+    e = R.Engine(R.Params(n=2, N=2048), 0)
+    try:
+        e.load_bk_torus(bk)
+        e.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        trlwe = np.empty((4, 2 * P.N), np.uint32)
+        trlwe[0] = 0x7DF7C000      # digits +31 (after the offset: top of the range) in every row
+        trlwe[1] = 0x82082000      # digits -32
+        trlwe[2] = np.where(np.arange(2 * P.N) % 2 == 0, 0x7DF7C000, 0x82082000).astype(np.uint32)
+        trlwe[3] = 0x7DF7C000
+        idx = np.array([0, 0, 1, 1], np.int32)
+        out = e.external_product_batch(idx, trlwe)
+        exp = np.stack([orc.external_product(P, pl, None, bk[i * w:(i + 1) * w], t) for i, t in zip(idx, trlwe)])
+        assert np.array_equal(out.reshape(exp.shape), exp)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("steps", [1, 2, 9])
+def test_ntt2048_blind_rotate_prefix_is_exact(ntt2048, orc, steps):
+    P, K, e = ntt2048
+    c0, c1 = K.encrypt_bits([0, 1, 1]), K.encrypt_bits([1, 1, 0])
+    t = np.stack([orc.gate_linear(P, orc.NAND, a, b) for a, b in zip(c0, c1)])
+    acc = e.blind_rotate_batch(t, steps)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    exp = np.stack([orc.blind_rotate(P, pl, None, K.bk_t, x, steps) for x in t])
+    assert np.array_equal(acc.reshape(exp.shape), exp)
+
+
+def test_ntt2048_gates_exact_and_all_shapes_agree(ntt2048, orc):
+    import os
+    import rustfhe_amd as R
+    P, K, e = ntt2048
+    rng = np.random.default_rng(2050)
+    G = 1100                                  # > 4 gates per CU
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
+    out = e.gate_batch(R.NAND, c0, c1)
+    assert K.decrypt_bits(out) == list(1 - (b0 & b1))
+    for k in (1, 5, 256, 257, 513, 769, 1024, 1025):
+        assert np.array_equal(e.gate_batch(R.NAND, c0[:k], c1[:k]), out[:k]), k
+    # whole gates against the oracle's exact backend (schoolbook products: ~40 s of CPU per gate, one per thread)
+    nt = min(8, os.cpu_count() or 1)
+    pick = rng.choice(G, nt, replace=False)
+    exp, _ = orc.gate_batch_mt(P, orc.NAND, None, K.bk_t, K.ksk, c0[pick], c1[pick], nthreads=nt, backend=orc.BACKEND_EXACT)
+    assert np.array_equal(out[pick], exp)
+    o = e.gate_batch(R.XOR, c0[:64], c1[:64])
+    assert K.decrypt_bits(o) == list(b0[:64] ^ b1[:64])
