@@ -422,26 +422,24 @@ std::vector<double> ntt_device_table() {
     return t;
 }
 
-// N = 2048 (rtfhe_kernels_ntt_halves.hpp; scripts/ntt/model2048.py): [half][direction][1024]; the 1024-point transform of half H
-// uses zeta_{k' + (1 + H) 2^floor(log2 k')} of the 2048-point table; the pad entry holds the twiddle of the stage across the halves
+// N = 2048 (rtfhe_kernels_ntt_halves.hpp; scripts/ntt/model2048.py): [half][1024] forward tables; the 1024-point transform of
+// half H uses zeta_{k' + (1 + H) 2^floor(log2 k')} of the 2048-point table; the pad entry holds zeta_1 (the stage across the halves)
 std::vector<double> ntt_halves_device_table() {
     constexpr int N2 = 2048;
     const uint64_t psi = powmod_p(22, (ntt::P_U64 - 1) / (2 * N2));
-    std::vector<uint64_t> zeta(N2), zinv(N2);
-    for (int k = 1; k < N2; k++) { zeta[k] = powmod_p(psi, (uint64_t)bitrev(k, 11)); zinv[k] = powmod_p(zeta[k], ntt::P_U64 - 2); }
-    std::vector<double> t(NttHalvesTw::GLOBAL_TOTAL, 0.0);
-    for (int H = 0; H < 2; H++)
-        for (int dir = 0; dir < 2; dir++) {
-            const std::vector<uint64_t>& z = dir ? zinv : zeta;
-            std::vector<uint64_t> sub(ntt::N);
-            for (int kp = 1; kp < ntt::N; kp++) {
-                int top = 0; while ((2 << top) <= kp) top++;
-                sub[kp] = z[kp + ((1 + H) << top)];
-            }
-            double* d = t.data() + (size_t)(2 * H + dir) * NttHalvesTw::TABLE;
-            ntt_fill_table(d, sub);
-            d[NttHalvesTw::CROSS] = centred_p(z[1]);
+    std::vector<uint64_t> zeta(N2);
+    for (int k = 1; k < N2; k++) zeta[k] = powmod_p(psi, (uint64_t)bitrev(k, 11));
+    std::vector<double> t(NttHalvesTw::TOTAL, 0.0);
+    for (int H = 0; H < 2; H++) {
+        std::vector<uint64_t> sub(ntt::N);
+        for (int kp = 1; kp < ntt::N; kp++) {
+            int top = 0; while ((2 << top) <= kp) top++;
+            sub[kp] = zeta[kp + ((1 + H) << top)];
         }
+        double* d = t.data() + (size_t)H * NttHalvesTw::TABLE;
+        ntt_fill_table(d, sub);
+        d[NttHalvesTw::CROSS] = centred_p(zeta[1]);
+    }
     return t;
 }
 
@@ -462,7 +460,7 @@ int ntt_prepare(rtfhe_ctx* ctx) {
     int grid = (polys + W - 1) / W; if (grid > 2048) grid = 2048;
     if (halves) {
         NttHalvesBkArgs a{ctx->d_ntt_tw, ctx->d_bk_torus, ctx->d_ntt_bk, polys, 2 * ctx->p.l, ninv};
-        const size_t lds = (size_t)(2 * NttHalvesTw::TABLE + W * ntt::XSLOTS) * sizeof(double);
+        const size_t lds = (size_t)(NttHalvesTw::TOTAL + W * ntt::XSLOTS) * sizeof(double);
         if (int rc = allow_lds(ctx, k_ntt_bk_halves<W>, lds)) return rc;
         hipLaunchKernelGGL(k_ntt_bk_halves<W>, dim3(grid), dim3(64 * W), lds, ctx->stream, a);
     } else {
@@ -530,18 +528,21 @@ int launch_bootstrap_ntt_halves_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s
     return 0;
 }
 
-// NTT backend at N = 2048: the same ladder (4 gates per CU in whole rounds, 1 / 2 / 3 per workgroup for a remainder)
+// NTT backend at N = 2048: the same ladder (NTT_HALVES_ROUND gates per CU in whole rounds, fewer per workgroup for a remainder)
+#ifndef NTT_HALVES_ROUND
+#define NTT_HALVES_ROUND 4
+#endif
 int launch_bootstrap_ntt_halves(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * 2048 : (size_t)a.n + 1;
-    const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
+    const size_t cus = (size_t)ctx->num_cus, round = NTT_HALVES_ROUND * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
     if (full)
-        if (int rc = launch_bootstrap_ntt_halves_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (int rc = launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
     const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
-    if (rem <= cus) return launch_bootstrap_ntt_halves_g<1>(ctx, tail, s);
-    if (rem <= 2 * cus) return launch_bootstrap_ntt_halves_g<2>(ctx, tail, s);
-    if (rem <= 3 * cus) return launch_bootstrap_ntt_halves_g<3>(ctx, tail, s);
+    if (rem <= cus || NTT_HALVES_ROUND == 1) return launch_bootstrap_ntt_halves_g<1>(ctx, tail, s);
+    if (rem <= 2 * cus || NTT_HALVES_ROUND == 2) return launch_bootstrap_ntt_halves_g<2>(ctx, tail, s);
+    if (rem <= 3 * cus || NTT_HALVES_ROUND == 3) return launch_bootstrap_ntt_halves_g<3>(ctx, tail, s);
     return launch_bootstrap_ntt_halves_g<4>(ctx, tail, s);
 }
 

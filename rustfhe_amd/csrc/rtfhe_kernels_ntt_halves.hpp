@@ -17,28 +17,29 @@
 // scripts/ntt/model2048.py runs this construction on exact integers (equal to the schoolbook negacyclic product on random and
 // extreme inputs, every intermediate below 2^53).  Outputs are bit-identical to the oracle's exact_int backend.
 //
-// LDS: 16 KiB of accumulator per gate; passes 1 and 2 of the four tables (two halves x two directions) in LDS, the per-lane
-// pass-3 entries (6 KiB per table) are read from global memory.
+// Tables: only the two halves' FORWARD tables exist (16 KiB of LDS): the inverse transform of half H reads the forward table of
+// half 1 - H with the block index reversed (ntt::inverse_rev: zeta_{nb+b}^-1 = -zeta_{nb+(nb-1-b)}), and the last stage's
+// twiddle is zeta_1^-1 = -zeta_1.  With 16 KiB of accumulator per gate four gates per CU fit (154 KiB).
 #pragma once
+
+#ifndef NH_SB
+#define NH_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 
 #include "rtfhe_kernels_ntt.hpp"
 
 namespace rtfhe {
 
 struct NttHalvesTw {
-    // global table, doubles: [half][direction][ntt::TW_DIR_PAD]; the pad entry (index ntt::TW_DIR) holds the twiddle of the stage
-    // across the halves: zeta_1 (forward) / zeta_1^-1 (inverse)
+    // doubles: [half][ntt::TW_DIR_PAD]: the forward table of the half's 1024-point transform; the pad entry (index ntt::TW_DIR)
+    // holds zeta_1, the twiddle of the stage across the halves
     static constexpr int CROSS = ntt::TW_DIR;
     static constexpr int TABLE = ntt::TW_DIR_PAD;
-    static constexpr int GLOBAL_TOTAL = 4 * TABLE;
-    // LDS copy: [half][direction][SMALL]: passes 1 and 2 (entries 0 .. TW_P3 - 1) and the cross twiddle at TW_P3
-    static constexpr int SMALL = 256;
-    static_assert(ntt::TW_P3 == SMALL - 1, "passes 1 and 2 + one entry");
-    static constexpr int LDS_TOTAL = 4 * SMALL;
+    static constexpr int TOTAL = 2 * TABLE;
 };
 
 struct NttHalvesLds {
-    static constexpr size_t TW = (size_t)NttHalvesTw::LDS_TOTAL * sizeof(double);
+    static constexpr size_t TW = (size_t)NttHalvesTw::TOTAL * sizeof(double);
     static constexpr size_t XB = (size_t)ntt::XSLOTS * sizeof(double);
     static_assert(ntt::XSLOTS >= ntt::N, "an exchange buffer must hold one half");
     __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }
@@ -51,32 +52,31 @@ __device__ __forceinline__ const double2* ntt_halves_bk_row(const double* bk_i, 
     return reinterpret_cast<const double2*>(bk_i + ((size_t)((row * 2 + comp) * 2 + H) * ntt::N)) + lane;
 }
 
-// the tables of one wave: tws = LDS copy of its half ([direction][SMALL]), twg = global table of its half ([direction][TABLE])
+// the tables of one wave: fwd = forward table of its half, mir = forward table of the other half (read by the inverse transform)
 struct NttHalvesTables {
-    const double* fwd_s;
-    const double* inv_s;
-    const double* fwd_g;
-    const double* inv_g;
-    __device__ __forceinline__ NttHalvesTables(const double* lds, const double* glob, int H)
-        : fwd_s(lds + (size_t)(2 * H) * NttHalvesTw::SMALL), inv_s(lds + (size_t)(2 * H + 1) * NttHalvesTw::SMALL),
-          fwd_g(glob + (size_t)(2 * H) * NttHalvesTw::TABLE), inv_g(glob + (size_t)(2 * H + 1) * NttHalvesTw::TABLE) {}
+    const double* fwd;
+    const double* mir;
+    __device__ __forceinline__ NttHalvesTables(const double* lds, int H)
+        : fwd(lds + (size_t)H * NttHalvesTw::TABLE), mir(lds + (size_t)(1 - H) * NttHalvesTw::TABLE) {}
 };
 
 __device__ __forceinline__ void ntt_halves_load_tables(double* lds, const double* glob, int tid, int nthreads) {
-    for (int idx = tid; idx < NttHalvesTw::LDS_TOTAL; idx += nthreads) {
-        const int t = idx / NttHalvesTw::SMALL, e = idx % NttHalvesTw::SMALL;
-        lds[idx] = glob[t * NttHalvesTw::TABLE + (e < ntt::TW_P3 ? e : NttHalvesTw::CROSS)];
-    }
+    for (int idx = tid; idx < NttHalvesTw::TOTAL; idx += nthreads) lds[idx] = glob[idx];
 }
 
 // One external product (CMUX = false: acc <- BK_i (x) acc) or one CMUX step (acc += BK_i (x) ((X^r - 1) acc)) by the two waves of a
 // gate.  Every wave of the workgroup must call it (workgroup barriers inside).
 template <int L, int BGBIT, bool CMUX>
-__device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const double* __restrict__ bk_i,
+__device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const __amdgpu_buffer_rsrc_t bk_rsrc, int bk_off,
                                                 const NttHalvesTables& t, double* __restrict__ myx, const double* __restrict__ otx,
                                                 int lane0, int H) {
     constexpr int LOGN = 11, N = 2048, HN = 1024, R = ntt::R;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    auto ld2 = [&](int voff, int soff) {
+        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, voff, soff, 0);
+        return make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+    };
     uint32_t u0[R], u1[R];
     auto gather = [&](const uint32_t* poly, int lane) {
 #pragma unroll
@@ -96,7 +96,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
         double s0[R], s1[R];
 #pragma unroll
         for (int m = 0; m < R; m++) { s0[m] = 0.0; s1[m] = 0.0; }
-        const double zc = t.fwd_s[ntt::TW_P3];
+        const double zc = t.fwd[NttHalvesTw::CROSS];
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
             double x[R];
@@ -106,29 +106,37 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
                 const double tt = ntt::modmul(d1, zc);         // |d1| <= Bg/2: the quotient is exact, |tt| <= P/2
                 x[m] = H ? d0 - tt : d0 + tt;
             }
-            const double2* b0p = ntt_halves_bk_row(bk_i, h * L + jj, 0, H, lane);
-            const double2* b1p = ntt_halves_bk_row(bk_i, h * L + jj, 1, H, lane);
             double2 b0[R / 2], b1[R / 2];
+            ntt::forward_a(x, t.fwd, myx, lane);
+            // key rows through a buffer resource (scalar row offset + one per-lane VGPR + immediates, see k_bootstrap_pair): component 0
+            // requested under the last pass, component 1 under component 0's products (all 64 registers of key rows requested up
+            // front cost 30 spilled registers: 45.0 vs 42.4 ms per 1024 gates)
+            const int s0off = __builtin_amdgcn_readfirstlane(bk_off + (((h * L + jj) * 2 + 0) * 2 + H) * ntt::N * 8);
+            const int s1off = s0off + 2 * ntt::N * 8;
+            NH_SB;
 #pragma unroll
-            for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
-            ntt::forward_a(x, t.fwd_s, myx, lane);
-            ntt::forward_b(x, t.fwd_g, myx, lane);
+            for (int q = 0; q < R / 2; q++) b0[q] = ld2(lane * 16 + q * 1024, s0off);
+            NH_SB;
+            ntt::forward_b(x, t.fwd, myx, lane);
+            NH_SB;
 #pragma unroll
-            for (int q = 0; q < R / 2; q++) {
-                s0[2 * q] += ntt::modmul(x[2 * q], b0[q].x);     s0[2 * q + 1] += ntt::modmul(x[2 * q + 1], b0[q].y);
-                s1[2 * q] += ntt::modmul(x[2 * q], b1[q].x);     s1[2 * q + 1] += ntt::modmul(x[2 * q + 1], b1[q].y);
-            }
+            for (int q = 0; q < R / 2; q++) b1[q] = ld2(lane * 16 + q * 1024, s1off);
+            NH_SB;
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) { s0[2 * q] += ntt::modmul(x[2 * q], b0[q].x);     s0[2 * q + 1] += ntt::modmul(x[2 * q + 1], b0[q].y); }
+            NH_SB;
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) { s1[2 * q] += ntt::modmul(x[2 * q], b1[q].x);     s1[2 * q + 1] += ntt::modmul(x[2 * q + 1], b1[q].y); }
         }
         // the a-polynomial's words leave the accumulator before the b-rows' results go into it (the partner's gather is ordered
         // before its own next barrier in the same way)
         if (h == 0) gather(accbuf + N, lane);
-        const double zi = t.inv_s[ntt::TW_P3];
 #pragma unroll 1
         for (int comp = 0; comp < 2; comp++) {
             double x[R];
 #pragma unroll
             for (int m = 0; m < R; m++) x[m] = comp ? s1[m] : s0[m];
-            ntt::inverse(x, t.inv_s, t.inv_g, myx, lane);
+            ntt::inverse_rev(x, t.mir, myx, lane);
             // x[m] = sub-coefficient lane + 64 m of this half (u on wave 0, v on wave 1), |x| <= P/2
 #pragma unroll
             for (int m = 0; m < R; m++) myx[lane + 64 * m] = x[m];
@@ -137,7 +145,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 const double o = otx[lane + 64 * m];
-                const double v = H ? ntt::normalize(ntt::modmul(o - x[m], zi)) : ntt::normalize(x[m] + o);
+                const double v = H ? ntt::normalize(ntt::modmul(x[m] - o, zc)) : ntt::normalize(x[m] + o);   // zeta_1^-1 (u - v) = zeta_1 (v - u)
                 const uint32_t w = ntt::to_torus(v);
                 if (CMUX || h == 1) poly[lane + 64 * m] += w;
                 else poly[lane + 64 * m] = w;
@@ -149,7 +157,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
 
 struct NttHalvesArgs {
     BootstrapArgs b;          // tw and bk of `b` are unused here
-    const double* ntt_tw;     // [NttHalvesTw::GLOBAL_TOTAL]
+    const double* ntt_tw;     // [NttHalvesTw::TOTAL]
     const double* ntt_bk;     // layout above
 };
 
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = wave % GATES, H = wave / GATES;          // the two halves of a gate share a SIMD (waves w, w + GATES)
     ntt_halves_load_tables(tw, args.ntt_tw, tid, NT);
-    const NttHalvesTables tables(tw, args.ntt_tw, H);
+    const NttHalvesTables tables(tw, H);
 
     const int g_raw = blockIdx.x * GATES + slot;
     const int g = g_raw < a.count ? g_raw : a.count - 1;
@@ -196,11 +204,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
     }
     __syncthreads();
 
-    const size_t trgsw_doubles = (size_t)2 * L * 2 * N;
+    // key rows through a buffer resource based at the current step's TRGSW (the whole key exceeds a 32-bit byte offset)
+    constexpr size_t trgsw_doubles = (size_t)2 * L * 2 * N;
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        ntt_halves_step<L, BGBIT, true>(accbuf, r, args.ntt_bk + (size_t)i * trgsw_doubles, tables, myx, otx, lane0, H);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(args.ntt_bk + (size_t)i * trgsw_doubles), 0,
+                                                                            (int)(trgsw_doubles * 8), 0x00020000);
+        ntt_halves_step<L, BGBIT, true>(accbuf, r, rs, 0, tables, myx, otx, lane0, H);
     }
 
     if (a.mode == MODE_BLIND_ROTATE) {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
 }
 
 struct NttHalvesBkArgs {
-    const double* ntt_tw;       // [NttHalvesTw::GLOBAL_TOTAL]
+    const double* ntt_tw;       // [NttHalvesTw::TOTAL]
     const uint32_t* bk_torus;   // [n][2][2l][N]
     double* ntt_bk;
     int32_t count;              // polynomials
@@ -263,8 +274,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_ntt_bk_halves(const NttHalves
     extern __shared__ __align__(16) unsigned char smem[];
     double* tw = reinterpret_cast<double*>(smem);                   // forward tables of both halves, whole
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int idx = tid; idx < 2 * NttHalvesTw::TABLE; idx += 64 * WAVES)
-        tw[idx] = a.ntt_tw[(size_t)(2 * (idx / NttHalvesTw::TABLE)) * NttHalvesTw::TABLE + idx % NttHalvesTw::TABLE];
+    ntt_halves_load_tables(tw, a.ntt_tw, tid, 64 * WAVES);
     __syncthreads();
     double* xbuf = tw + 2 * NttHalvesTw::TABLE + (size_t)wave * ntt::XSLOTS;
     const double zc = tw[NttHalvesTw::CROSS];
@@ -307,15 +317,17 @@ __global__ __launch_bounds__(128, 1) void k_external_product_ntt_halves(const Nt
     const int tid = threadIdx.x, lane = tid & 63;
     const int H = __builtin_amdgcn_readfirstlane(tid >> 6);
     ntt_halves_load_tables(tw, a.ntt_tw, tid, 128);
-    const NttHalvesTables tables(tw, a.ntt_tw, H);
+    const NttHalvesTables tables(tw, H);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(smem + NttHalvesLds::TW);
     double* xb0 = reinterpret_cast<double*>(smem + NttHalvesLds::TW + (size_t)2 * N * 4);
     double* xb1 = xb0 + ntt::XSLOTS;
     const int g = blockIdx.x;                       // grid = count
     for (int c = tid; c < 2 * N; c += 128) accbuf[c] = a.trlwe[(size_t)g * 2 * N + c];
     __syncthreads();
-    ntt_halves_step<L, BGBIT, false>(accbuf, 0, a.ntt_bk + (size_t)a.bk_index[g] * ((size_t)2 * L * 2 * N), tables,
-                                     H ? xb1 : xb0, H ? xb0 : xb1, lane, H);
+    constexpr size_t trgsw_doubles = (size_t)2 * L * 2 * N;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ntt_bk + (size_t)a.bk_index[g] * trgsw_doubles), 0,
+                                                                        (int)(trgsw_doubles * 8), 0x00020000);
+    ntt_halves_step<L, BGBIT, false>(accbuf, 0, rs, 0, tables, H ? xb1 : xb0, H ? xb0 : xb1, lane, H);
     __syncthreads();
     for (int c = tid; c < 2 * N; c += 128) a.out[(size_t)g * 2 * N + c] = accbuf[c];
 }

@@ -177,6 +177,64 @@ __device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict
     inverse(x, tw, tw, xbuf, lane);
 }
 
+// The inverse transform read from a FORWARD table.  psi^N = -1 gives zeta_{nb + b}^-1 = -zeta_{nb + (nb - 1 - b)} on every level
+// (nb blocks): the inverse twiddles are the forward ones with the block index reversed inside each level, negated -- and
+// (u - v) (-z) = (v - u) z, so the negation costs nothing.  `twm` is the forward table of the mirrored transform: the transform's
+// own forward table for a whole N = 1024 transform, the OTHER half's for a half of the N = 2048 transform (block b of half H
+// is block H nb + b of the level, its mirror lies in half 1 - H).  Same values bit for bit as inverse() with an inverse table.
+__host__ __device__ constexpr int rev15(int e) {      // entry nb - 1 + idx of a 15-entry level list -> nb - 1 + (nb - 1 - idx)
+    int nb = 1;
+    while (2 * nb <= e + 1) nb *= 2;
+    return nb - 1 + (nb - 1 - (e + 1 - nb));
+}
+template <int MB>
+__device__ __forceinline__ void inv_stage_rev(double (&x)[R], const double* z) {
+    constexpr int h = 1 << MB, nb = R >> (MB + 1);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & h) continue;
+        const double u = x[m], v = x[m | h];
+        x[m] = u + v;
+        x[m | h] = modmul(v - u, z[nb - 1 + (m >> (MB + 1))]);
+    }
+}
+__device__ __forceinline__ void inverse_rev(double (&x)[R], const double* __restrict__ twm, double* __restrict__ xbuf, int lane) {
+    double z1[15], z2[15], z3[12];
+    const int rl = 63 - lane;
+#pragma unroll
+    for (int e = 0; e < 4; e++) z3[e] = twm[TW_P3 + (3 - e) * 64 + rl];
+#pragma unroll
+    for (int e = 0; e < 8; e++) z3[4 + e] = twm[TW_P3 + (4 + 7 - e) * 64 + rl];
+    normalize_all(x);
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double u = x[m], v = x[m + 1];
+        x[m] = u + v;
+        x[m + 1] = modmul(v - u, z3[4 + (m >> 1)]);
+    }
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & 2) continue;
+        const double u = x[m], v = x[m | 2];
+        x[m] = u + v;
+        x[m | 2] = modmul(v - u, z3[m >> 2]);
+    }
+#pragma unroll
+    for (int e = 0; e < 15; e++) z2[e] = twm[TW_P2 + rev15(e) * 16 + 15 - (lane >> 2)];
+    exchange<3, 2>(x, xbuf, lane);
+    inv_stage_rev<0>(x, z2);
+    normalize_all(x);
+    inv_stage_rev<1>(x, z2); inv_stage_rev<2>(x, z2); inv_stage_rev<3>(x, z2);
+    normalize_all(x);
+#pragma unroll
+    for (int e = 0; e < 15; e++) z1[e] = twm[TW_P1 + rev15(e)];
+    exchange<2, 1>(x, xbuf, lane);
+    inv_stage_rev<0>(x, z1); inv_stage_rev<1>(x, z1); inv_stage_rev<2>(x, z1);
+    normalize_all(x);
+    inv_stage_rev<3>(x, z1);
+    normalize_all(x);
+}
+
 // exact integer (|x| < 2^51) -> torus word: the low 32 bits of the two's-complement value
 __device__ __forceinline__ uint32_t to_torus(double x) {
     return (uint32_t)__double_as_longlong(x + 6755399441055744.0);
