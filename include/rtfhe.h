@@ -85,7 +85,7 @@ typedef enum {
 typedef enum {
     RTFHE_BACKEND_FFT64_MIRROR = 0,  /* default: FP64 transform mirroring the reference's spqlios operation for operation;
                                         outputs bit-identical to the reference CPU path */
-    RTFHE_BACKEND_NTT_EXACT = 1      /* exact negacyclic NTT mod P = 2^50 - 16383 (N = 1024): reference semantics of the exact
+    RTFHE_BACKEND_NTT_EXACT = 1      /* exact negacyclic NTT mod P = 2^50 - 16383 (N = 1024 and 2048): reference semantics of the exact
                                         Polynomial::cross (utils/src/math.rs:238-257); bit-identical to an exact-integer
                                         evaluation, decrypt-level parity with the reference's FFT path */
 } rtfhe_backend;
