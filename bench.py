@@ -60,6 +60,31 @@ def dp_wave_instr_per_cmux(N=1024, l=3):
     return {"add_mul": arith, "cvt_trunc": cvt, "total": arith + cvt, "transform": transform, "mac_row": mac}
 
 
+def ntt_dp_wave_instr_per_cmux(N=1024, l=3):
+    """FP64-rate VALU wave-instructions of one CMUX step on the exact-integer NTT backend (rustfhe_amd/csrc/rtfhe_ntt.hpp,
+    rtfhe_kernels_ntt.hpp, rtfhe_kernels_ntt_halves.hpp; checked against the built kernels' ISA by tests/test_bench_launcher.py).
+    A modular product is 6 instructions (mul, fma, mul, rndne, fma, add), a renormalisation 3 (mul, rndne, fma); one wave
+    transforms 1024 points, 16 per lane: 10 stages x 8 butterflies x (product + 2 sums)."""
+    R, stages = 16, 10
+    modmul, norm = 6, 3
+    fwd = stages * (R // 2) * (modmul + 2) + 2 * R * norm               # renormalised after stages 5 and 10
+    inv = stages * (R // 2) * (modmul + 2) + 5 * R * norm               # on entry and after stages 3, 6, 9, 10
+    mac = 2 * R * (modmul + 1)                                          # both components of a key row
+    if N == 1024:
+        # two waves per gate, each: l rows (digit cvt, transform, products), the swapped component's add, one inverse, magic add
+        wave = l * (R + fwd + mac) + R + inv + R
+        return {"total": 2 * wave, "per_wave": wave, "loop_static": (R + fwd + mac) + R + inv + R, "forward": fwd, "inverse": inv, "mac_row": mac}
+    if N == 2048:
+        # two waves per transform: per polynomial and row both halves' digits (2R cvt), the stage across the halves (R products +
+        # R sums), the half's transform and products; four inverse transforms per step (b-rows and a-rows separately), each with the
+        # last stage across the halves: wave 0 R sums + R renormalisations, wave 1 R differences + R products + R renormalisations
+        row = 2 * R + R * (modmul + 1) + fwd + mac
+        cross0, cross1 = R + R * norm + R, R + R * modmul + R * norm + R
+        total = 2 * (2 * l * row) + 4 * (2 * inv + cross0 + cross1)
+        return {"total": total, "row": row, "forward": fwd, "inverse": inv, "mac_row": mac}
+    raise ValueError("N")
+
+
 def kernel_src_hash():
     """Identifies the device code a PMC profile was taken with (profiles/pmc_traffic.json is refused when it differs)."""
     h = hashlib.sha256()
@@ -349,10 +374,19 @@ def run_rank(args):
                                     "vs_hbm_peak": round(ALG_BYTES_PER_GATE * G / launch_s / HBM_PEAK, 4), "hbm_peak_GBps": HBM_PEAK / 1e9},
             }
         else:
-            achieved = ALG_BYTES_PER_GATE * G / launch_s
-            line["roofline"] = {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                "frac": round(achieved / HBM_PEAK, 4), "traffic": None, "kernel": kernel, "avg_launch_ms": round(1e3 * launch_s, 3),
-                                "alg_bytes_per_gate": ALG_BYTES_PER_GATE, "gates_per_launch": G, "launches_per_batch": round(launches / args.steps, 2)}
+            # same ceiling (FP64-rate vector issue; the NTT's v_fma_f64 count as one instruction each)
+            nops = ntt_dp_wave_instr_per_cmux(params.N, params.l)
+            dp_gate = nops["total"] * params.n
+            achieved = dp_gate * 64 * G / launch_s
+            line["roofline"] = {
+                "bound": "fp64-valu", "achieved": round(achieved / 1e12, 3), "peak": round(FP64_VALU_PEAK / 1e12, 3), "unit": "Tops/s",
+                "frac": round(achieved / FP64_VALU_PEAK, 4), "traffic": None, "kernel": kernel, "avg_launch_ms": round(1e3 * launch_s, 3),
+                "peak_is": "%d CU x %d SIMD x %d DP lanes/clk x %.1f GHz (MI355X_MICROARCH.md max clock)" % (CUS, SIMDS_PER_CU, DP_LANES_PER_CLK, CLOCK_HZ / 1e9),
+                "dp_wave_instr_per_gate": dp_gate, "dp_wave_instr_per_cmux": nops, "gates_per_launch": G,
+                "launches_per_batch": round(launches / args.steps, 2),
+                "hbm_algorithmic": {"bytes_per_gate": ALG_BYTES_PER_GATE, "GBps": round(ALG_BYTES_PER_GATE * G / launch_s / 1e9, 2),
+                                    "vs_hbm_peak": round(ALG_BYTES_PER_GATE * G / launch_s / HBM_PEAK, 4), "hbm_peak_GBps": HBM_PEAK / 1e9},
+            }
         # measured HBM-side bytes per launch (rocprofv3 --pmc passes): only from a profile of THIS device code and launch shape
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):

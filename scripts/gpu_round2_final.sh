@@ -13,6 +13,8 @@ RTFHE_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --workload c
 timeout -k 10 300 python bench.py --backend ntt-exact --no-cpu-baseline > $O/bench_ntt_exact.json 2> $O/bench_ntt.err; echo "ntt rc=$?"; cut -c1-200 $O/bench_ntt_exact.json
 RTFHE_SKIP_STAGES=1 timeout -k 10 300 python scripts/sweep.py 1,256,512,768,1024,1280,2048,4096,8192 > $O/sweep.log 2>&1; echo "sweep rc=$?"; grep -v amdgpu.ids $O/sweep.log
 RTFHE_N=2048 RTFHE_SKIP_STAGES=1 timeout -k 10 300 python scripts/sweep.py 1,1024,2048 > $O/sweep_n2048.log 2>&1; echo "sweep2048 rc=$?"; grep -v amdgpu.ids $O/sweep_n2048.log
+RTFHE_BACKEND=ntt RTFHE_SKIP_STAGES=1 timeout -k 10 300 python scripts/sweep.py 1,256,512,1024,2048 > $O/sweep_ntt.log 2>&1; echo "sweep ntt rc=$?"; grep -v amdgpu.ids $O/sweep_ntt.log
+RTFHE_N=2048 RTFHE_BACKEND=ntt RTFHE_SKIP_STAGES=1 timeout -k 10 300 python scripts/sweep.py 1,256,1024,2048 > $O/sweep_ntt_n2048.log 2>&1; echo "sweep ntt2048 rc=$?"; grep -v amdgpu.ids $O/sweep_ntt_n2048.log
 timeout -k 10 300 python scripts/bench_circuit.py > $O/bench_circuit.log 2>&1; echo "circuit rc=$?"; grep -v amdgpu.ids $O/bench_circuit.log
 timeout -k 10 300 python scripts/host_rate.py > $O/host_rate.log 2>&1; echo "host_rate rc=$?"; grep -v amdgpu.ids $O/host_rate.log
 bash scripts/profile_gpu.sh r02 > $O/profile.log 2>&1; echo "profile rc=$?"; tail -3 $O/profile.log

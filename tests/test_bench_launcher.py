@@ -101,3 +101,28 @@ def test_dp_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
     per_wave_arith, per_wave_cvt = ops["add_mul"] // 2, ops["cvt_trunc"] // 2
     assert arith == per_wave_arith + 3 * ops["mac_row"], (arith, per_wave_arith)
     assert cvt == per_wave_cvt, (cvt, per_wave_cvt)
+
+
+def test_ntt_opcount_formula():
+    import bench
+    o = bench.ntt_dp_wave_instr_per_cmux(1024, 3)
+    assert o["forward"] == 736 and o["inverse"] == 880 and o["mac_row"] == 224
+    assert o["per_wave"] == 3840 and o["total"] == 7680 and o["loop_static"] == 1888
+    assert bench.ntt_dp_wave_instr_per_cmux(2048, 3)["total"] == 21312
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_ntt_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
+    """k_bootstrap_ntt_pair's step loop holds the row loop's body once (not unrolled) and the step's tail: the static count of
+    FP64-rate instructions must be the formula's one-row count."""
+    import bench
+    from rustfhe_amd import build as b
+    asm = tmp_path / "api.s"
+    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + \
+          ["--cuda-device-only", "-S", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"), "-o", str(asm)]
+    subprocess.check_call(cmd)
+    text = asm.read_text()
+    m = re.search(r"\n(_ZN5rtfhe20k_bootstrap_ntt_pairILi3ELi6ELi8ELi2ELi3ELi4E\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S)
+    assert m, "k_bootstrap_ntt_pair not found in the device assembly"
+    f64 = len(re.findall(r"^\s*v_\w+_f64", m.group(2), re.M))
+    assert f64 == bench.ntt_dp_wave_instr_per_cmux(1024, 3)["loop_static"], f64
