@@ -68,17 +68,20 @@ def ntt_dp_wave_instr_per_cmux(N=1024, l=3):
     R, stages = 16, 10
     modmul, norm = 6, 3
     fwd = stages * (R // 2) * (modmul + 2) + 2 * R * norm               # renormalised after stages 5 and 10
+    # decomposition digits times the first stage's single twiddle come from a 64-entry table in LDS (no conversion, no product)
+    fwd_digits = fwd - (R // 2) * modmul
     inv = stages * (R // 2) * (modmul + 2) + 5 * R * norm               # on entry and after stages 3, 6, 9, 10
     mac = 2 * R * (modmul + 1)                                          # both components of a key row
     if N == 1024:
         # two waves per gate, each: l rows (digit cvt, transform, products), the swapped component's add, one inverse, magic add
-        wave = l * (R + fwd + mac) + R + inv + R
-        return {"total": 2 * wave, "per_wave": wave, "loop_static": (R + fwd + mac) + R + inv + R, "forward": fwd, "inverse": inv, "mac_row": mac}
+        row = R // 2 + fwd_digits + mac                                 # conversions of the stage's other input only
+        wave = l * row + R + inv + R
+        return {"total": 2 * wave, "per_wave": wave, "loop_static": row + R + inv + R, "forward": fwd_digits, "inverse": inv, "mac_row": mac}
     if N == 2048:
         # two waves per transform: per polynomial and row both halves' digits (2R cvt), the stage across the halves (R products +
         # R sums), the half's transform and products; four inverse transforms per step (b-rows and a-rows separately), each with the
         # last stage across the halves: wave 0 R sums + R renormalisations, wave 1 R differences + R products + R renormalisations
-        row = 2 * R + R * (modmul + 1) + fwd + mac
+        row = R + R + fwd + mac                                         # R conversions, R sums of the stage across the halves (table)
         cross0, cross1 = R + R * norm + R, R + R * modmul + R * norm + R
         total = 2 * (2 * l * row) + 4 * (2 * inv + cross0 + cross1)
         return {"total": total, "row": row, "forward": fwd, "inverse": inv, "mac_row": mac}

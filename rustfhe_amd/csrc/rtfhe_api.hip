@@ -411,6 +411,15 @@ void ntt_fill_table(double* d, const std::vector<uint64_t>& z) {
     }
 }
 
+// digit table: entry e = (e as a signed 6-bit value) * zeta_1 mod P, centred
+void ntt_fill_digits(double* d, uint64_t zeta1) {
+    for (int e = 0; e < ntt::DIGITS; e++) {
+        const int sdig = e < ntt::DIGITS / 2 ? e : e - ntt::DIGITS;
+        const uint64_t mag = mulmod_p((uint64_t)(sdig < 0 ? -sdig : sdig), zeta1);
+        d[e] = centred_p(sdig < 0 ? (ntt::P_U64 - mag) % ntt::P_U64 : mag);
+    }
+}
+
 // N = 1024: zeta_k = psi^bitrev(k), psi a primitive 2048-th root of unity (22 generates F_P^*)
 std::vector<double> ntt_device_table() {
     const uint64_t psi = powmod_p(22, (ntt::P_U64 - 1) / (2 * ntt::N));
@@ -419,6 +428,7 @@ std::vector<double> ntt_device_table() {
     std::vector<double> t(ntt::TW_TOTAL, 0.0);
     ntt_fill_table(t.data(), zeta);
     ntt_fill_table(t.data() + ntt::TW_DIR_PAD, zinv);
+    ntt_fill_digits(t.data() + ntt::TW_DIG, zeta[1]);
     return t;
 }
 
@@ -440,6 +450,7 @@ std::vector<double> ntt_halves_device_table() {
         ntt_fill_table(d, sub);
         d[NttHalvesTw::CROSS] = centred_p(zeta[1]);
     }
+    ntt_fill_digits(t.data() + NttHalvesTw::DIG, zeta[1]);
     return t;
 }
 

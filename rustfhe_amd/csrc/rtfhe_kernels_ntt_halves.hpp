@@ -35,7 +35,8 @@ struct NttHalvesTw {
     // holds zeta_1, the twiddle of the stage across the halves
     static constexpr int CROSS = ntt::TW_DIR;
     static constexpr int TABLE = ntt::TW_DIR_PAD;
-    static constexpr int TOTAL = 2 * TABLE;
+    static constexpr int DIG = 2 * TABLE;          // [64]: (signed 6-bit digit) * zeta_1 mod P, centred (see ntt::TW_DIG)
+    static constexpr int TOTAL = DIG + ntt::DIGITS;
 };
 
 struct NttHalvesLds {
@@ -56,8 +57,9 @@ __device__ __forceinline__ const double2* ntt_halves_bk_row(const double* bk_i, 
 struct NttHalvesTables {
     const double* fwd;
     const double* mir;
+    const double* dig;
     __device__ __forceinline__ NttHalvesTables(const double* lds, int H)
-        : fwd(lds + (size_t)H * NttHalvesTw::TABLE), mir(lds + (size_t)(1 - H) * NttHalvesTw::TABLE) {}
+        : fwd(lds + (size_t)H * NttHalvesTw::TABLE), mir(lds + (size_t)(1 - H) * NttHalvesTw::TABLE), dig(lds + NttHalvesTw::DIG) {}
 };
 
 __device__ __forceinline__ void ntt_halves_load_tables(double* lds, const double* glob, int tid, int nthreads) {
@@ -72,6 +74,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
                                                 int lane0, int H) {
     constexpr int LOGN = 11, N = 2048, HN = 1024, R = ntt::R;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
+    static_assert((1 << BGBIT) == ntt::DIGITS, "the digit table has one entry per digit value");
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     auto ld2 = [&](int voff, int soff) {
         const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, voff, soff, 0);
@@ -102,8 +105,8 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
             double x[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
-                const double d0 = (double)decomp_digit(u0[m], BGBIT, jj), d1 = (double)decomp_digit(u1[m], BGBIT, jj);
-                const double tt = ntt::modmul(d1, zc);         // |d1| <= Bg/2: the quotient is exact, |tt| <= P/2
+                const double d0 = (double)decomp_digit(u0[m], BGBIT, jj);
+                const double tt = t.dig[ntt::digit_entry(u1[m], BGBIT, jj)];     // digit * zeta_1 mod P from the 64-entry table
                 x[m] = H ? d0 - tt : d0 + tt;
             }
             double2 b0[R / 2], b1[R / 2];
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_ntt_bk_halves(const NttHalves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ntt_halves_load_tables(tw, a.ntt_tw, tid, 64 * WAVES);
     __syncthreads();
-    double* xbuf = tw + 2 * NttHalvesTw::TABLE + (size_t)wave * ntt::XSLOTS;
+    double* xbuf = tw + NttHalvesTw::TOTAL + (size_t)wave * ntt::XSLOTS;
     const double zc = tw[NttHalvesTw::CROSS];
     for (int g = blockIdx.x * WAVES + wave; g < a.count; g += gridDim.x * WAVES) {
         const int32_t* src = reinterpret_cast<const int32_t*>(a.bk_torus) + (size_t)g * N;

@@ -38,7 +38,11 @@ constexpr int TW_P2 = TW_P1 + 15;
 constexpr int TW_P3 = TW_P2 + 15 * 16;
 constexpr int TW_DIR = TW_P3 + 12 * 64;   // 1023 = N - 1 zetas
 constexpr int TW_DIR_PAD = 1024;          // keep the inverse table 16-byte aligned
-constexpr int TW_TOTAL = 2 * TW_DIR_PAD;
+// digit table [64]: entry e = (e as a signed 6-bit digit) * zeta_1 mod P, centred.  The first forward stage multiplies decomposition
+// DIGITS (64 possible values, Bgbit = 6) by the single twiddle zeta_1: one LDS read replaces the conversion and the 6-instruction product
+constexpr int DIGITS = 64;
+constexpr int TW_DIG = 2 * TW_DIR_PAD;
+constexpr int TW_TOTAL = TW_DIG + DIGITS;
 constexpr int XSLOTS = GN::XSLOTS;        // 1088 doubles
 
 __device__ __forceinline__ double modmul(double a, double w) {
@@ -98,11 +102,13 @@ __device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xb
 // Forward transform in two parts so that a caller can issue its global loads between them (their registers are then
 // not live through passes 1 and 2).  in: layout L1 (x[m] = coefficient lane + 64 m), small integers or |x| < 2^32.
 // out: layout L3 (point (lane << 4) | m), normalised.  tw: LDS forward table.
+template <bool FIRST_STAGE_DONE = false>
 __device__ __forceinline__ void forward_a(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     double z1[15], z2[15];
 #pragma unroll
     for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
-    fwd_stage<3>(x, z1); fwd_stage<2>(x, z1); fwd_stage<1>(x, z1); fwd_stage<0>(x, z1);
+    if constexpr (!FIRST_STAGE_DONE) fwd_stage<3>(x, z1);
+    fwd_stage<2>(x, z1); fwd_stage<1>(x, z1); fwd_stage<0>(x, z1);
 #pragma unroll
     for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
     exchange<1, 2>(x, xbuf, lane);
@@ -134,6 +140,22 @@ __device__ __forceinline__ void forward_b(double (&x)[R], const double* __restri
 __device__ __forceinline__ void forward(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     forward_a(x, tw, xbuf, lane);
     forward_b(x, tw, xbuf, lane);
+}
+
+// The first stage on decomposition digits: x[m] = digit of coefficient lane + 64 m (m < 8) as a double, t[m] = the digit of coefficient
+// lane + 64 (m + 8) times zeta_1, read from the digit table (the same centred residue modmul() returns for so small an input).
+// forward_a<true> continues with stage 2.
+__device__ __forceinline__ void first_stage_digits(double (&x)[R], const double (&t)[R / 2]) {
+#pragma unroll
+    for (int m = 0; m < R / 2; m++) {
+        const double lo = x[m];
+        x[m] = lo + t[m];
+        x[m + R / 2] = lo - t[m];
+    }
+}
+// byte offset of a digit's entry in the digit table: field j (from the top) of the pre-masked word u = (x + M) ^ M, times 8
+__device__ __forceinline__ int digit_entry(uint32_t u, int bits, int j) {
+    return (int)__builtin_amdgcn_ubfe(u, (uint32_t)(32 - bits * (j + 1)), (uint32_t)bits);
 }
 
 // in: layout L3, |x| < 2^52.  out: layout L1, the centred residue (= the exact integer when |true value| < P/2).
