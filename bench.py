@@ -230,6 +230,11 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to stdout when its first communicator comes up
+    # (seen on ROCm 7: "RCCL version : ...", 5 lines).  Until the line is printed, file descriptor 1 points at stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # RTFHE_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
@@ -242,7 +247,13 @@ def run_rank(args):
     gpu = torch.device("cuda", dev)
     comm = gpu if backend == "nccl" else torch.device("cpu")      # where collectives run
     dist = None
-    if world > 1:
+    # RTFHE_BENCH_FORCE_PG=1: build the process group even for one rank (a 1-GPU box then still runs RCCL's communicator set-up,
+    # the key broadcast, the barriers and the max-reduction exactly as the N > 1 run does)
+    if world > 1 or os.environ.get("RTFHE_BENCH_FORCE_PG"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=gpu)
@@ -402,7 +413,10 @@ def run_rank(args):
                 line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json is from other device code or another launch shape: not quoted"
         if n_gpus == 1 and not args.no_cpu_baseline and mirror and not config3:
             line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

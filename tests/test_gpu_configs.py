@@ -257,3 +257,24 @@ def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch):
             assert np.array_equal(e.gate_batch(R.NAND, d0[:k], d1[:k]), ref[:k]), k
     finally:
         one.close()
+
+
+def test_bench_stdout_is_one_json_line_with_an_rccl_process_group():
+    """bench.py's contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first communicator comes
+    up: with RTFHE_BENCH_FORCE_PG=1 a single rank builds the RCCL process group (communicator, key broadcast, barriers,
+    max-reduction run as in the N > 1 job) and stdout must still be exactly the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTFHE_BENCH_FORCE_PG="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[:2000]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["outputs_decrypt_correctly"] and j["config"]["comm_backend"] == "nccl"
+    assert 0 < j["roofline"]["frac"] < 1
