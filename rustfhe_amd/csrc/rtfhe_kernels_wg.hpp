@@ -95,6 +95,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     // Software-pipelined: the values of step i + 1 are requested at the start of step i's I phase (6 of the 8 waves idle
     // there) and have landed by the barrier that ends it.
     cplx bkv[ROWS][2];
+#ifdef WG_BK_POINTER_LOADS
     auto load_bk = [&](int step, cplx (&dst)[ROWS][2]) {
         const cplx* bk_i = a.bk + (size_t)step * trgsw_cplx;
 #pragma unroll
@@ -103,6 +104,23 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             dst[j][1] = bk_i[(size_t)((j * 2 + 1) * R + wave) * 64 + lane];
         }
     };
+#else
+    // through a buffer resource: scalar offset of (step, row, component, wave) + one per-lane VGPR (see k_bootstrap_pair)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(a.bk), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
+    auto load_bk = [&](int step, cplx (&dst)[ROWS][2]) {
+        const int s0 = __builtin_amdgcn_readfirstlane((int)(((size_t)step * trgsw_cplx + (size_t)wave * 64) * sizeof(cplx)));
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16, s0 + (j * 2 + c) * R * 64 * (int)sizeof(cplx), 0);
+                dst[j][c] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+            }
+        }
+    };
+#endif
     if (a.steps > 0) load_bk(0, bkv);
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
