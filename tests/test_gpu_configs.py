@@ -31,6 +31,35 @@ def test_config3_per_gpu_shard_8192(engine, orc, params, keys):
     assert np.array_equal(engine.gate_batch(R.NAND, c0[:1000], c1[:1000]), out[:1000])
 
 
+def test_config3_whole_batch_65536_on_one_gpu(engine, orc, params, keys):
+    """BASELINE config 3 at its full size (65,536 gates), here on one GPU: every output decrypts; the eight contiguous ranges the
+    node's GPUs would take (8,192 each) computed on their own give the same words as the one big call; a random
+    sample is bit-exact against the oracle.  Device-resident input / output (333 MB in, 167 MB out)."""
+    import torch
+    import rustfhe_amd as R
+    from rustfhe_amd.shard import partition
+    G = 65536
+    rng = np.random.default_rng(65536)
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    d0 = torch.from_numpy(c0.view(np.int32)).cuda()
+    d1 = torch.from_numpy(c1.view(np.int32)).cuda()
+    do = torch.empty_like(d0)
+    st = torch.cuda.current_stream().cuda_stream
+    engine.gate_batch_dev(R.NAND, d0, d1, do, G, st)
+    engine.sync(st)
+    out = do.cpu().numpy().view(np.uint32)
+    assert keys.decrypt_bits(out) == list(1 - (b0 & b1))
+    part = torch.empty_like(d0)
+    for lo, hi in partition(G, 8):
+        engine.gate_batch_dev(R.NAND, d0[lo:hi], d1[lo:hi], part[lo:hi], hi - lo, st)
+    engine.sync(st)
+    assert torch.equal(part, do)
+    pick = rng.choice(G, 96, replace=False)
+    exp, _ = orc.gate_batch_mt(params, orc.NAND, keys.bk_f, None, keys.ksk, c0[pick], c1[pick], nthreads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(out[pick], exp)
+
+
 @pytest.fixture(scope="module")
 def setup2048(orc):
     import rustfhe_amd as R
