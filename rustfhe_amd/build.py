@@ -11,7 +11,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtfhe_hip.so")
 SOURCES = ["rtfhe_api.hip", "rtfhe_keygen.cpp", "rtfhe_wire.cpp"]
-DEPS = SOURCES + ["rtfhe_device.hpp", "rtfhe_kernels.hpp", "rtfhe_kernels_wg.hpp", "rtfhe_kernels_pair.hpp", "rtfhe_kernels_halves.hpp", "rtfhe_kernels_ntt.hpp", "rtfhe_ntt.hpp", os.path.join("..", "..", "include", "rtfhe.h")]
+
+
+def _deps():
+    """Every source and header under csrc/ plus the public header: a changed header must rebuild the library."""
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp", ".h"))]
+    return files + [os.path.join(HERE, "..", "include", "rtfhe.h")]
+
+
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
 
@@ -20,7 +27,7 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force=False, verbose=False, extra=()):

@@ -19,6 +19,7 @@
 #include "rtfhe_kernels_halves.hpp"
 #include "rtfhe_kernels_ntt.hpp"
 #include "rtfhe_kernels_ntt_halves.hpp"
+#include "rtfhe_kernels_ntt_wg.hpp"
 
 using namespace rtfhe;
 
@@ -279,7 +280,14 @@ int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
     const void* key = reinterpret_cast<const void*>(kernel);
     auto it = ctx->lds_allowed.find(key);
     if (it != ctx->lds_allowed.end() && it->second >= bytes) return 0;
-    HIPCHECK(ctx, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        hipFuncAttributes fa{};
+        const hipError_t e2 = hipFuncGetAttributes(&fa, key);
+        return fail(ctx, RTFHE_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize = ") + std::to_string(bytes) + "): " + hipGetErrorString(e) +
+                    (e2 == hipSuccess ? " [kernel: static LDS " + std::to_string(fa.sharedSizeBytes) + ", regs " + std::to_string(fa.numRegs) +
+                                        ", max threads " + std::to_string(fa.maxThreadsPerBlock) + "]" : std::string(" [hipFuncGetAttributes: ") + hipGetErrorString(e2) + "]"));
+    }
     ctx->lds_allowed[key] = bytes;
     return 0;
 }
@@ -510,6 +518,18 @@ int launch_bootstrap_ntt_pair_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) 
     return 0;
 }
 
+// NTT backend, one gate per 8-wave workgroup (the latency shape)
+int launch_bootstrap_ntt_wg(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_ntt_wg<3, 6, 8, 2, KSQ>;
+    const size_t lds = NttWgLds::bytes(b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    NttBootstrapArgs a{b, ctx->d_ntt_tw, ctx->d_ntt_bk};
+    hipLaunchKernelGGL(k, dim3(b.count), dim3(512), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
 // NTT backend, two waves per gate.  Whole rounds of 4 gates per CU in one launch; a remainder runs with 1 / 2 / 3 gates per
 // workgroup (one workgroup per CU): with fewer gates per CU a gate's two waves share their SIMDs with fewer other waves -- a
 // circuit wave of 1-3 gates takes 0.67 x the time of a full round instead of all of it.
@@ -521,7 +541,7 @@ int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         if (int rc = launch_bootstrap_ntt_pair_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
     const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
-    if (rem <= cus) return launch_bootstrap_ntt_pair_g<1>(ctx, tail, s);
+    if (rem <= cus) return ctx->force_waves == 2 ? launch_bootstrap_ntt_pair_g<1>(ctx, tail, s) : launch_bootstrap_ntt_wg(ctx, tail, s);
     if (rem <= 2 * cus) return launch_bootstrap_ntt_pair_g<2>(ctx, tail, s);
     if (rem <= 3 * cus) return launch_bootstrap_ntt_pair_g<3>(ctx, tail, s);
     return launch_bootstrap_ntt_pair_g<4>(ctx, tail, s);
@@ -704,6 +724,7 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 2>, NttPairLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 1>, NttPairLds::bytes(1, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt<3, 6, 8, 2, KSQ, 4>, ntt_lds_bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_ntt_wg<3, 6, 8, 2, KSQ>, NttWgLds::bytes(npad))) return rc;
     } else {
         if (int rc = allow_lds(ctx, k_bootstrap<11, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<11>(4, npad, bootstrap_dual_xbuf(11, 4)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 4>, HalvesLds::bytes(4, npad))) return rc;

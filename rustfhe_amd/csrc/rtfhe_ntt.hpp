@@ -142,6 +142,34 @@ __device__ __forceinline__ void forward(double (&x)[R], const double* __restrict
     forward_b(x, tw, xbuf, lane);
 }
 
+// forward_b cut at its exchange, for a hand-off between two waves (k_bootstrap_ntt_wg): the first wave writes the exchange buffer
+// (forward_b_send), the second reads it and runs pass 3 (forward_b_receive).  The caller orders the two (release / acquire).
+__device__ __forceinline__ void forward_b_send(const double (&x)[R], double* __restrict__ xbuf, int lane) {
+#pragma unroll
+    for (int m = 0; m < R; m++) xbuf[GN::f2(GN::pos2(lane, m))] = x[m];
+}
+__device__ __forceinline__ void forward_b_receive(double (&x)[R], const double* __restrict__ tw, const double* __restrict__ xbuf, int lane) {
+    double z3[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) z3[e] = tw[TW_P3 + e * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < R; m++) x[m] = xbuf[GN::f2(GN::pos3(lane, m))];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        if (m & 2) continue;
+        const double t = modmul(x[m | 2], z3[m >> 2]);
+        x[m | 2] = x[m] - t;
+        x[m] = x[m] + t;
+    }
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double t = modmul(x[m + 1], z3[4 + (m >> 1)]);
+        x[m + 1] = x[m] - t;
+        x[m] = x[m] + t;
+    }
+    normalize_all(x);
+}
+
 // The first stage on decomposition digits: x[m] = digit of coefficient lane + 64 m (m < 8) as a double, t[m] = the digit of coefficient
 // lane + 64 (m + 8) times zeta_1, read from the digit table (the same centred residue modmul() returns for so small an input).
 // forward_a<true> continues with stage 2.
