@@ -207,3 +207,38 @@ def test_ntt2048_gates_exact_and_all_shapes_agree(ntt2048, orc):
     assert np.array_equal(out[pick], exp)
     o = e.gate_batch(R.XOR, c0[:64], c1[:64])
     assert K.decrypt_bits(o) == list(b0[:64] ^ b1[:64])
+
+
+def test_ntt_backend_runs_netlists(ntt_engine, orc, params, keys):
+    """Circuit waves on the NTT backend: netlist-mode launches (wire table, per-gate opcodes) go through k_bootstrap_ntt_wg for
+    small waves and the two-waves-per-gate kernel for large ones; one HIP-graph submission replays the same words; replica 0 is
+    bit-exact, gate by gate, against the oracle's exact backend walking the same netlist."""
+    from rustfhe_amd.circuit import CircuitRunner, ripple_carry_adder
+    net = ripple_carry_adder(4, nand_only=True)
+    pl = orc.Plan(params.N, orc.BACKEND_EXACT)
+    for reps in (3, 200):                     # wave sizes 3..9 gates (latency kernel) and 200..600 (throughput kernels)
+        rng = np.random.default_rng(900 + reps)
+        bits = rng.integers(0, 2, (reps, 8))
+        cts = keys.encrypt_bits(bits.reshape(-1)).reshape(reps, 8, params.n + 1)
+        g, w = CircuitRunner(ntt_engine, net, reps), CircuitRunner(ntt_engine, net, reps)
+        g.set_inputs(cts)
+        w.set_inputs(cts)
+        a = g.run(graph=True).outputs()
+        b = w.run(graph=False).outputs()
+        assert np.array_equal(a, b)
+        dec = np.array(keys.decrypt_bits(a.reshape(-1, params.n + 1))).reshape(reps, 5)
+        A = (bits[:, :4] * (1 << np.arange(4))).sum(axis=1)
+        B = (bits[:, 4:] * (1 << np.arange(4))).sum(axis=1)
+        assert np.array_equal((dec * (1 << np.arange(5))).sum(axis=1), A + B)
+        if reps == 3:
+            wires = [None, None] + list(cts[0])
+            triv = np.zeros((2, params.n + 1), np.uint32)
+            triv[0, -1], triv[1, -1] = 0xE0000000, 0x20000000
+            wires[0], wires[1] = triv[0], triv[1]
+            for op, x, y in net.gates[:6]:            # ~10 s of schoolbook products per gate on the CPU: the first six gates
+                wires.append(orc.gate(params, pl, op, None, keys.bk_t, keys.ksk, wires[x], wires[y]))
+            base = 2 + net.num_inputs
+            for k in range(6):
+                assert np.array_equal(w.wire(base + k)[0], wires[base + k]), k
+        g.close()
+        w.close()
