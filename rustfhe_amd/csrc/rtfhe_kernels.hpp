@@ -171,10 +171,14 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
 // then gathers t/2 rows per coefficient of which 15/16 are non-zero instead of t rows of which 3/4 are: 9.8 MB instead of
 // 15.6 MB per gate through the L2 (the key switch is L2-bandwidth bound: all gates of a launch reach it together), for a
 // 2.5x larger table (156 MB, still resident in the Infinity Cache next to the bootstrapping key).
-constexpr int KS_GROUP = 2;
+#ifndef RTFHE_KS_GROUP        // A/B builds: 1 = the reference's per-level rows (no pre-summing)
+#define RTFHE_KS_GROUP 2
+#endif
+constexpr int KS_GROUP = RTFHE_KS_GROUP;
+static_assert(KS_GROUP == 1 || KS_GROUP == 2, "single levels or pairs");
 __host__ __device__ constexpr int ks_dev_rows(int N, int t, int basebit) { return N * (t / KS_GROUP) * ((1 << (basebit * KS_GROUP)) - 1); }
 
-template <int LOGN, int KS_T, int KS_BB, int KSQ, int KS_UI = 4>
+template <int LOGN, int KS_T, int KS_BB, int KSQ, int KS_UI = 2 * KS_GROUP>
 __device__ __forceinline__ void ks_accumulate(const uint32_t* __restrict__ aprime, int i_begin, int i_end,
                                               const uint32_t* __restrict__ ksk, int ksw, uint4 (&sum)[KSQ], int lane) {
     constexpr int N = 1 << LOGN;
@@ -223,11 +227,14 @@ struct KskCombineArgs {
 template <int KS_T, int KS_BB>
 __global__ __launch_bounds__(256) void k_ksk_combine(const KskCombineArgs a) {
     constexpr int BASE1 = (1 << KS_BB) - 1, PT = KS_T / KS_GROUP, PBB = KS_BB * KS_GROUP, PBASE1 = (1 << PBB) - 1;
-    static_assert(KS_GROUP == 2, "pairs of levels");
     const int rows = a.N * PT * PBASE1, zero_src = a.N * KS_T * BASE1;
     for (int r = blockIdx.x; r <= rows; r += gridDim.x) {
         uint32_t* dst = a.out + (size_t)r * a.ksw;
         if (r == rows) { for (int w = threadIdx.x; w < a.ksw; w += blockDim.x) dst[w] = 0u; continue; }
+        if constexpr (KS_GROUP == 1) {      // A/B builds: the reference's rows as they are
+            for (int w = threadIdx.x; w < a.ksw; w += blockDim.x) dst[w] = a.raw[(size_t)r * a.ksw + w];
+            continue;
+        }
         const int c = r % PBASE1 + 1, ip = r / PBASE1, p = ip % PT, i = ip / PT;
         const int d0 = c >> KS_BB, d1 = c & BASE1;
         const int s0 = d0 ? ((i * KS_T + 2 * p) * BASE1 + d0 - 1) : zero_src;
