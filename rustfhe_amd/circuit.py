@@ -204,6 +204,34 @@ def ripple_carry_adder(nbits=8, nand_only=True):
     return net
 
 
+def prefix_adder(nbits=8):
+    """The same nbits + nbits -> nbits + carry function as ripple_carry_adder, as a parallel-prefix (Kogge-Stone) netlist of the
+    reference's AND / OR / XOR gates (hom_and / hom_or / hom_xor, hom_nand/src/tfhe.rs:27-71).  A dependency wave of up to a few hundred
+    gates costs the engine what one gate costs, so only the DEPTH of a netlist matters for one addition: generate / propagate (one
+    level), log2(nbits) prefix stages of two levels each -- (G, P) o (G', P') = (G | (P & G'), P & P') -- and the sum XORs: depth
+    at most 2 + 2 log2(nbits); 7 for 8 bits (the low groups finish early) against 17 for the ripple-carry netlist of the same gates
+    (more gates: 70 against 40)."""
+    net = Netlist()
+    a = net.inputs(nbits)
+    b = net.inputs(nbits)
+    p = [net.xor(a[i], b[i]) for i in range(nbits)]       # propagate (also the half sums)
+    G = [net.and_(a[i], b[i]) for i in range(nbits)]      # generate
+    P = list(p)
+    d = 1
+    while d < nbits:
+        t = {i: net.and_(P[i], G[i - d]) for i in range(d, nbits)}
+        last = 2 * d >= nbits                               # group propagates are not needed after the last stage
+        P2 = {} if last else {i: net.and_(P[i], P[i - d]) for i in range(d, nbits)}
+        G = [G[i] if i < d else net.or_(G[i], t[i]) for i in range(nbits)]
+        P = [P[i] if i < d or last else P2[i] for i in range(nbits)]
+        d *= 2
+    net.output(p[0])
+    for i in range(1, nbits):
+        net.output(net.xor(p[i], G[i - 1]))                # G[i - 1] = carry into bit i
+    net.output(G[nbits - 1])
+    return net
+
+
 # ---- execution on the engine ------------------------------------------------------------------------
 
 class CircuitRunner:

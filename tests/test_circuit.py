@@ -41,6 +41,20 @@ def test_adder_netlists_on_plain_bits():
         assert level.get(a, 0) < level[base + g] and level.get(b, 0) < level[base + g]
 
 
+def test_prefix_adder_netlist_on_plain_bits():
+    from rustfhe_amd.circuit import prefix_adder, ripple_carry_adder
+    rng = np.random.default_rng(2)
+    for nbits in (1, 2, 3, 4, 8, 13):
+        net = prefix_adder(nbits)
+        for _ in range(200):
+            a, b = int(rng.integers(0, 1 << nbits)), int(rng.integers(0, 1 << nbits))
+            bits = [(a >> i) & 1 for i in range(nbits)] + [(b >> i) & 1 for i in range(nbits)]
+            out = net.evaluate_plain(bits)
+            assert sum(v << i for i, v in enumerate(out)) == a + b, (nbits, a, b)
+    d = prefix_adder(8).describe()
+    assert d["depth"] == 7 and d["gates"] == 70 and ripple_carry_adder(8, False).describe()["depth"] == 17
+
+
 def test_mux_netlist_plain():
     from rustfhe_amd.circuit import Netlist
     net = Netlist()
@@ -179,3 +193,36 @@ def test_circuit_runner_reports_a_skipped_gate_at_run(engine, keys):
         assert ei.value.code == R._ffi.ERR_INVALID
         run.close()
     engine.sync()                                         # reported once: the context is clean again
+
+
+@pytest.mark.gpu
+def test_prefix_adder_8bit_on_gpu(engine, orc, params, keys):
+    """The parallel-prefix adder of the reference's AND / OR / XOR gates: correct sums, replica 0 bit-exact gate by gate against the
+    oracle, same words through the HIP-graph submission."""
+    from rustfhe_amd.circuit import CircuitRunner, prefix_adder
+    net = prefix_adder(8)
+    reps = 16
+    rng = np.random.default_rng(80)
+    A, B = rng.integers(0, 256, reps), rng.integers(0, 256, reps)
+    A[0], B[0], A[1], B[1] = 255, 255, 255, 1
+    bits = np.array([[(a >> i) & 1 for i in range(8)] + [(b >> i) & 1 for i in range(8)] for a, b in zip(A, B)])
+    cts = keys.encrypt_bits(bits.reshape(-1)).reshape(reps, 16, params.n + 1)
+    run = CircuitRunner(engine, net, reps)
+    run.set_inputs(cts)
+    out = run.run(graph=True).outputs()
+    dec = np.array(keys.decrypt_bits(out.reshape(-1, params.n + 1))).reshape(reps, 9)
+    assert np.array_equal((dec * (1 << np.arange(9))).sum(axis=1), A + B)
+    plain = CircuitRunner(engine, net, reps)
+    plain.set_inputs(cts)
+    assert np.array_equal(plain.run(graph=False).outputs(), out)
+    pl = orc.Plan(params.N)
+    w = [None, None] + list(cts[0])
+    triv = np.zeros((2, params.n + 1), np.uint32)
+    triv[0, -1], triv[1, -1] = 0xE0000000, 0x20000000
+    w[0], w[1] = triv[0], triv[1]
+    for op, x, y in net.gates:
+        w.append(orc.gate(params, pl, op, keys.bk_f, None, keys.ksk, w[x], w[y]))
+    for k, wi in enumerate(net.outputs):
+        assert np.array_equal(out[0, k], w[wi])
+    run.close()
+    plain.close()
