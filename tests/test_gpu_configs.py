@@ -11,6 +11,20 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 
+def test_config2_batch_1024_every_output_bit_exact(engine, orc, params, keys):
+    """BASELINE config 2 (the bench workload): 1,024 independent gates on one GPU, EVERY output compared bit for bit with the CPU
+    oracle (all host threads, one independent gate stream each)."""
+    import rustfhe_amd as R
+    G = 1024
+    rng = np.random.default_rng(1024)
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    out = engine.gate_batch(R.NAND, c0, c1)
+    exp, _ = orc.gate_batch_mt(params, orc.NAND, keys.bk_f, None, keys.ksk, c0, c1, nthreads=min(64, os.cpu_count() or 1))
+    assert np.array_equal(out, exp)
+    assert keys.decrypt_bits(out) == list(1 - (b0 & b1))
+
+
 def test_config3_per_gpu_shard_8192(engine, orc, params, keys):
     import rustfhe_amd as R
     G = 8192
