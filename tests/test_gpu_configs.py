@@ -48,7 +48,7 @@ def test_config3_per_gpu_shard_8192(engine, orc, params, keys):
 def test_config3_whole_batch_65536_on_one_gpu(engine, orc, params, keys):
     """BASELINE config 3 at its full size (65,536 gates), here on one GPU: every output decrypts; the eight contiguous ranges the
     node's GPUs would take (8,192 each) computed on their own give the same words as the one big call; a random
-    sample is bit-exact against the oracle.  Device-resident input / output (333 MB in, 167 MB out)."""
+    sample of 1,024 outputs is bit-exact against the oracle.  Device-resident input / output (333 MB in, 167 MB out)."""
     import torch
     import rustfhe_amd as R
     from rustfhe_amd.shard import partition
@@ -69,8 +69,8 @@ def test_config3_whole_batch_65536_on_one_gpu(engine, orc, params, keys):
         engine.gate_batch_dev(R.NAND, d0[lo:hi], d1[lo:hi], part[lo:hi], hi - lo, st)
     engine.sync(st)
     assert torch.equal(part, do)
-    pick = rng.choice(G, 96, replace=False)
-    exp, _ = orc.gate_batch_mt(params, orc.NAND, keys.bk_f, None, keys.ksk, c0[pick], c1[pick], nthreads=min(32, os.cpu_count() or 1))
+    pick = rng.choice(G, 1024, replace=False)
+    exp, _ = orc.gate_batch_mt(params, orc.NAND, keys.bk_f, None, keys.ksk, c0[pick], c1[pick], nthreads=min(64, os.cpu_count() or 1))
     assert np.array_equal(out[pick], exp)
 
 
