@@ -33,11 +33,23 @@ def stale():
 def build(force=False, verbose=False, extra=()):
     if not (force or stale()):
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # several ranks of one job may get here together: one of them builds (into a temporary name, renamed when complete), the others
+    # wait on the lock and find the library fresh
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or stale():
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            cmd = [hipcc] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd).replace(tmp, LIB), flush=True)
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     return LIB
 
 
