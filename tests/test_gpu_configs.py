@@ -321,3 +321,52 @@ def test_bench_stdout_is_one_json_line_with_an_rccl_process_group():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["outputs_decrypt_correctly"] and j["config"]["comm_backend"] == "nccl"
     assert 0 < j["roofline"]["frac"] < 1
+
+
+def test_two_contexts_on_two_host_threads_and_context_churn(params, keys, gold_gate):
+    """The ABI's threading rule is one context per host thread.  Two contexts driven from two threads at the same time (ctypes drops the
+    GIL inside the call) give the golden words; creating and destroying contexts in a loop leaves the device's free memory where it
+    was (keys, staging buffers, graphs and streams are all released)."""
+    import threading
+    import torch
+    import rustfhe_amd as R
+    free0 = None
+    for round_ in range(6):
+        e = R.Engine(R.Params(), 0)
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        rows = np.flatnonzero(np.array(gold_gate["ops"]) == R.NAND)[:3]
+        out = e.gate_batch(R.NAND, gold_gate["in0"][rows], gold_gate["in1"][rows])
+        assert np.array_equal(out, gold_gate["out"][rows])
+        e.close()
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if round_ == 1:
+            free0 = free                      # after the first rounds the runtime's own pools have settled
+        elif round_ > 1:
+            assert free >= free0 - (8 << 20), (free0, free)
+    engines = []
+    for _ in range(2):
+        e = R.Engine(R.Params(), 0)
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        engines.append(e)
+    results, errors = [None, None], []
+    nand = np.array(gold_gate["ops"]) == R.NAND                       # the fixture's rows carry their own opcodes
+    g_in0, g_in1, g_out = np.array(gold_gate["in0"])[nand], np.array(gold_gate["in1"])[nand], np.array(gold_gate["out"])[nand]
+
+    def work(k):
+        try:
+            for _ in range(5):
+                results[k] = engines[k].gate_batch(R.NAND, g_in0, g_in1)
+                assert np.array_equal(results[k], g_out[:len(g_in0)])
+        except Exception as ex:               # noqa: BLE001 -- reported in the main thread
+            errors.append(ex)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engines:
+        e.close()
+    assert not errors, errors
