@@ -197,7 +197,9 @@ int rtfhe_tlwe_phase(const rtfhe_params *p, const int32_t *key0, const uint32_t 
 int rtfhe_keys_write(const char *path, const rtfhe_params *p, const int32_t *key0, const int32_t *key1,
                      const uint32_t *bk, const uint32_t *ksk);          /* null sections are left out */
 int rtfhe_keys_read_header(const char *path, rtfhe_params *p, uint32_t *flags);
-int rtfhe_keys_read(const char *path, int32_t *key0, int32_t *key1, uint32_t *bk, uint32_t *ksk);   /* null = skip */
+/* Buffers are sized for the parameter set rtfhe_keys_read_header returns (call it first); null = skip that section; asking for a
+ * section the file does not hold (see flags) fails. */
+int rtfhe_keys_read(const char *path, int32_t *key0, int32_t *key1, uint32_t *bk, uint32_t *ksk);
 int rtfhe_tlwe_write(const char *path, int32_t n, const uint32_t *cts, size_t count);
 int rtfhe_tlwe_read(const char *path, int32_t *n, uint64_t *count, uint32_t *cts /* NULL: header only */, size_t capacity);
 

@@ -59,7 +59,7 @@ int rtfhe_keys_read_header(const char* path, rtfhe_params* p, uint32_t* flags) {
     return ok ? 0 : RTFHE_ERR_INVALID;
 }
 
-// buffers sized from the header; a section absent from the file or a null buffer is skipped.  Verifies the checksum.
+// buffers sized from the header; a null buffer skips its section, asking for a section the file lacks fails.  Verifies the checksum.
 int rtfhe_keys_read(const char* path, int32_t* key0, int32_t* key1, uint32_t* bk, uint32_t* ksk) {
     if (!path) return RTFHE_ERR_INVALID;
     FILE* f = std::fopen(path, "rb");
@@ -73,6 +73,8 @@ int rtfhe_keys_read(const char* path, int32_t* key0, int32_t* key1, uint32_t* bk
         for (size_t done = 0; done < bytes;) { const size_t c = bytes - done < skip.size() ? bytes - done : skip.size(); if (!rd(f, h, skip.data(), c)) return false; done += c; }
         return true;
     };
+    // a section the caller asks for but the file does not hold is an error (its buffer would stay unwritten)
+    if (ok && (((key0 || key1) && !(flags & 4)) || (bk && !(flags & 1)) || (ksk && !(flags & 2)))) ok = false;
     if (ok && (flags & 4)) ok = section(key0, (size_t)p.n * 4) && section(key1, (size_t)p.N * 4);
     if (ok && (flags & 1)) ok = section(bk, bk_words(p) * 4);
     if (ok && (flags & 2)) ok = section(ksk, ksk_words(p) * 4);
