@@ -14,8 +14,8 @@ key0, key1, bk, ksk = R.keygen(P, 20211003)
 eng = R.Engine(P, 0)
 eng.load_bk_torus(bk); eng.load_ksk(ksk)
 rng = np.random.default_rng(0)
-for kind in ("nand-only", "xor/and/or", "prefix xor/and/or"):
-    net = prefix_adder(8) if kind.startswith("prefix") else ripple_carry_adder(8, kind == "nand-only")
+for kind in ("nand-only", "xor/and/or", "prefix nand-only", "prefix xor/and/or"):
+    net = prefix_adder(8, kind.endswith("nand-only")) if kind.startswith("prefix") else ripple_carry_adder(8, kind == "nand-only")
     d = net.describe()
     for reps in (1, 32, 256, 1024):
         A, B = rng.integers(0, 256, reps), rng.integers(0, 256, reps)

@@ -53,6 +53,17 @@ def test_prefix_adder_netlist_on_plain_bits():
             assert sum(v << i for i, v in enumerate(out)) == a + b, (nbits, a, b)
     d = prefix_adder(8).describe()
     assert d["depth"] == 7 and d["gates"] == 70 and ripple_carry_adder(8, False).describe()["depth"] == 17
+    # NAND gates only (the reference's nander evaluates NAND trees): same function, depth 11 against the ripple-carry netlist's 20
+    from rustfhe_amd.circuit import NAND
+    for nbits in (1, 2, 3, 4, 8, 13):
+        net = prefix_adder(nbits, nand_only=True)
+        assert {op for op, _, _ in net.gates} == {NAND}
+        for _ in range(200):
+            a, b = int(rng.integers(0, 1 << nbits)), int(rng.integers(0, 1 << nbits))
+            bits = [(a >> i) & 1 for i in range(nbits)] + [(b >> i) & 1 for i in range(nbits)]
+            assert sum(v << i for i, v in enumerate(net.evaluate_plain(bits))) == a + b, (nbits, a, b)
+    d = prefix_adder(8, nand_only=True).describe()
+    assert d["depth"] == 11 and d["gates"] == 162 and ripple_carry_adder(8, True).describe()["depth"] == 20
 
 
 def test_mux_netlist_plain():
@@ -226,3 +237,9 @@ def test_prefix_adder_8bit_on_gpu(engine, orc, params, keys):
         assert np.array_equal(out[0, k], w[wi])
     run.close()
     plain.close()
+    # the NAND-only form: correct sums through one graph submission
+    nn = CircuitRunner(engine, prefix_adder(8, nand_only=True), reps)
+    nn.set_inputs(cts)
+    dec = np.array(keys.decrypt_bits(nn.run(graph=True).outputs().reshape(-1, params.n + 1))).reshape(reps, 9)
+    assert np.array_equal((dec * (1 << np.arange(9))).sum(axis=1), A + B)
+    nn.close()
