@@ -177,7 +177,14 @@ def test_config1_example_and_sharded_path_on_one_gpu(engine, params, keys):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):      # in-process: a GPU-initialised process must not spawn GPU children here
         runpy.run_path(os.path.join(root, "examples", "homnand_bench.py"), run_name="__main__")
+        import sys
+        argv, sys.argv = sys.argv, ["nander_adder.py", "200", "57", "(1|0)&!(1^1)"]
+        try:
+            runpy.run_path(os.path.join(root, "examples", "nander_adder.py"), run_name="__main__")
+        finally:
+            sys.argv = argv
     text = buf.getvalue()
+    assert text.count("200 + 57 = 257") == 3 and "(1|0)&!(1^1)" in text, text[-2000:]
     assert "all truth tables ok" in text, text[-2000:]
     assert text.count("micro-seconds") == 18                 # the reference example's 18 bootstraps
     rng = np.random.default_rng(91)
