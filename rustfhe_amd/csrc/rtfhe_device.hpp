@@ -62,6 +62,27 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One double to / from an exchange buffer as its OWN ds_write_b64 / ds_read_b64.  Plain accesses with constant offsets from
+// one base are paired by the compiler into ds_write2_b64 / ds_read2_b64, and on gfx950 a ds_read2_b64 occupies the LDS for
+// 8 cycles where two ds_read_b64 take 2 + 2 (ds_write2_b64: 13 against 6 + 6) -- MI355X_MICROARCH.md, LDS table; measured
+// here: one 16-double exchange at two waves per SIMD costs the CU 81 cycles unpaired against 101 paired
+// (scripts/ubench/lds_forms.hip, profiles/r03/lds_forms.log), the headline kernel 7.35 -> 7.12 ms per 1024 gates.  A relaxed
+// wavefront-scope atomic access lowers to exactly the plain instruction and is never paired.  -DRTFHE_LDS_PAIRED: A/B builds.
+__device__ __forceinline__ void lds_st(double* p, double v) {
+#ifdef RTFHE_LDS_PAIRED
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
+}
+__device__ __forceinline__ double lds_ld(const double* p) {
+#ifdef RTFHE_LDS_PAIRED
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // butterflies (one register-index bit MB at a time; h = 1 << MB; q = m & (h-1) selects the twiddle)
 // ---------------------------------------------------------------------------------------------
@@ -78,7 +99,13 @@ struct Tw {
 };
 
 // DIF, twiddled: x0' = x0 + x1 ; x1' = (x0 - x1) * w      (spqlios-fft-impl.cpp:546-569)
-template <int R, int MB>
+// TRIV0: the caller vouches that w[0] is exactly (1.0, +0.0) -- true of every table the reference builders produce for a
+// stage's first entry, cos(0) / sin(0); the host refuses any other table (check_trivial_twiddles, rtfhe_api.hip) -- and the
+// butterfly with q = 0 then skips its six multiply / add instructions: d * 1.0 == d and d - e * 0.0 == d for every finite d, e
+// EXCEPT in the sign of a zero result.  The sign of a zero never reaches a torus word: zero + x == x, zero * w is a zero, there
+// is no division or comparison on the path and Torus32(int64_t(+-0.0)) == 0.  Only kernels whose outputs are torus words use it;
+// the stage-level transform kernels, whose outputs ARE spectra, keep TRIV0 = false and stay byte-identical to the reference.
+template <int R, int MB, bool TRIV0 = false>
 __device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], const cplx* w) {
     constexpr int h = 1 << MB;
 #pragma unroll
@@ -88,6 +115,7 @@ __device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], c
         const double sr = re[m] + re[m1], si = im[m] + im[m1];
         const double dr = re[m] - re[m1], di = im[m] - im[m1];
         re[m] = sr; im[m] = si;
+        if (TRIV0 && q == 0) { re[m1] = dr; im[m1] = di; continue; }
         double a = dr * w[q].x, b = di * w[q].y;
         re[m1] = a - b;
         a = dr * w[q].y; b = di * w[q].x;
@@ -99,13 +127,19 @@ __device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], c
 // CONJ: w holds the FORWARD table's (c, s) and the stage multiplies by its conjugate (c, -s) -- what the reference's inverse
 // table contains (the host checks the two tables are exact conjugates before a kernel relies on it).  x * (-s) == -(x * s)
 // and a - (-b) == a + b exactly, so t0 + t3 / t2 - t1 are the bits the reference's t0 - t3' / t1' + t2 give.
-template <int R, int MB, bool CONJ = false>
+template <int R, int MB, bool CONJ = false, bool TRIV0 = false>
 __device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], const cplx* w) {
     constexpr int h = 1 << MB;
 #pragma unroll
     for (int m = 0; m < R; m++) {
         if (m & h) continue;
         const int m1 = m | h, q = m & (h - 1);
+        if (TRIV0 && q == 0) {     // t = x1 * (1, 0) = x1 up to the sign of a zero (see fwd_stage_tw)
+            const double ar = re[m], ai = im[m], tr = re[m1], ti = im[m1];
+            re[m] = ar + tr; im[m] = ai + ti;
+            re[m1] = ar - tr; im[m1] = ai - ti;
+            continue;
+        }
         const double t0 = re[m1] * w[q].x, t1 = re[m1] * w[q].y, t2 = im[m1] * w[q].x, t3 = im[m1] * w[q].y;
         const double tr = CONJ ? t0 + t3 : t0 - t3, ti = CONJ ? t2 - t1 : t1 + t2;
         const double ar = re[m], ai = im[m];
@@ -179,13 +213,13 @@ struct P12 {   // passes 1 and 2: all LR register bits, twiddled; w = the pass's
     }
 };
 
-template <int R, int NLOW, int MBTOP>
+template <int R, int NLOW, int MBTOP, bool TRIV = false>
 struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uniform twiddles), bits 1, 0 special
     __device__ __forceinline__ static void fwd(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 2) {
             constexpr int h = 1 << MBTOP;
-            fwd_stage_tw<R, MBTOP>(re, im, w + (NLOW - 2 * h));
-            P3<R, NLOW, MBTOP - 1>::fwd(re, im, w);
+            fwd_stage_tw<R, MBTOP, TRIV>(re, im, w + (NLOW - 2 * h));
+            P3<R, NLOW, MBTOP - 1, TRIV>::fwd(re, im, w);
         } else {
             fwd_stage_size4<R>(re, im);
             stage_size2<R>(re, im);
@@ -195,8 +229,8 @@ struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uni
     __device__ __forceinline__ static void inv(double (&re)[R], double (&im)[R], const cplx* w) {
         if constexpr (MBTOP >= 2) {
             constexpr int h = 1 << MBTOP;
-            P3<R, NLOW, MBTOP - 1>::template inv<CONJ>(re, im, w);
-            inv_stage_tw<R, MBTOP, CONJ>(re, im, w + (NLOW - 2 * h));
+            P3<R, NLOW, MBTOP - 1, TRIV>::template inv<CONJ>(re, im, w);
+            inv_stage_tw<R, MBTOP, CONJ, TRIV>(re, im, w + (NLOW - 2 * h));
         } else {
             stage_size2<R>(re, im);
             inv_stage_size4<R>(re, im);
@@ -242,45 +276,45 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
         constexpr int sw = stride(FROM), sr = stride(TO);
 #ifndef ABL_NOXW
 #pragma unroll
-        for (int m = 0; m < R; m++) xbuf[bw + sw * m] = re[m];
+        for (int m = 0; m < R; m++) lds_st(&xbuf[bw + sw * m], re[m]);
 #pragma unroll
-        for (int m = 0; m < R; m++) xim[bw + sw * m] = im[m];
+        for (int m = 0; m < R; m++) lds_st(&xim[bw + sw * m], im[m]);
 #endif
         wave_lds_sync();
 #ifndef ABL_NOXR
 #pragma unroll
         for (int m = 0; m < R / 2; m++) {
-            re[m] = xbuf[br + sr * m]; re[m + R / 2] = xbuf[br + sr * (m + R / 2)];
-            im[m] = xim[br + sr * m];  im[m + R / 2] = xim[br + sr * (m + R / 2)];
+            re[m] = lds_ld(&xbuf[br + sr * m]); re[m + R / 2] = lds_ld(&xbuf[br + sr * (m + R / 2)]);
+            im[m] = lds_ld(&xim[br + sr * m]);  im[m + R / 2] = lds_ld(&xim[br + sr * (m + R / 2)]);
         }
 #endif
         wave_lds_sync();
     } else if constexpr (DUAL) {
         double* xim = ximbuf ? ximbuf : xbuf + G::XSLOTS;   // second buffer: caller's, or right behind the first
 #pragma unroll
-        for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
+        for (int m = 0; m < R; m++) lds_st(&xbuf[slot(FROM, m)], re[m]);
 #pragma unroll
-        for (int m = 0; m < R; m++) xim[slot(FROM, m)] = im[m];
+        for (int m = 0; m < R; m++) lds_st(&xim[slot(FROM, m)], im[m]);
         wave_lds_sync();
         // first stage of the next pass pairs m with m + R/2
 #pragma unroll
         for (int m = 0; m < R / 2; m++) {
-            re[m] = xbuf[slot(TO, m)]; re[m + R / 2] = xbuf[slot(TO, m + R / 2)];
-            im[m] = xim[slot(TO, m)];  im[m + R / 2] = xim[slot(TO, m + R / 2)];
+            re[m] = lds_ld(&xbuf[slot(TO, m)]); re[m + R / 2] = lds_ld(&xbuf[slot(TO, m + R / 2)]);
+            im[m] = lds_ld(&xim[slot(TO, m)]);  im[m + R / 2] = lds_ld(&xim[slot(TO, m + R / 2)]);
         }
         wave_lds_sync();
     } else {
 #pragma unroll
-        for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = re[m];
+        for (int m = 0; m < R; m++) lds_st(&xbuf[slot(FROM, m)], re[m]);
         wave_lds_sync();
 #pragma unroll
-        for (int m = 0; m < R; m++) re[m] = xbuf[slot(TO, m)];
+        for (int m = 0; m < R; m++) re[m] = lds_ld(&xbuf[slot(TO, m)]);
         wave_lds_sync();
 #pragma unroll
-        for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = im[m];
+        for (int m = 0; m < R; m++) lds_st(&xbuf[slot(FROM, m)], im[m]);
         wave_lds_sync();
 #pragma unroll
-        for (int m = 0; m < R; m++) im[m] = xbuf[slot(TO, m)];
+        for (int m = 0; m < R; m++) im[m] = lds_ld(&xbuf[slot(TO, m)]);
         wave_lds_sync();
     }
 }
@@ -297,9 +331,9 @@ __device__ __forceinline__ void exchange_write_dual(const double (&re)[Geo<LOGN>
         return (FROM + TO == 3) ? G::f1(pos) : G::f2(pos);
     };
 #pragma unroll
-    for (int m = 0; m < R; m++) xbuf[slot(m)] = re[m];
+    for (int m = 0; m < R; m++) lds_st(&xbuf[slot(m)], re[m]);
 #pragma unroll
-    for (int m = 0; m < R; m++) xim[slot(m)] = im[m];
+    for (int m = 0; m < R; m++) lds_st(&xim[slot(m)], im[m]);
 }
 template <int LOGN, int FROM, int TO>
 __device__ __forceinline__ void exchange_read_dual(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
@@ -312,8 +346,8 @@ __device__ __forceinline__ void exchange_read_dual(double (&re)[Geo<LOGN>::R], d
     };
 #pragma unroll
     for (int m = 0; m < R / 2; m++) {
-        re[m] = xbuf[slot(m)]; re[m + R / 2] = xbuf[slot(m + R / 2)];
-        im[m] = xim[slot(m)];  im[m + R / 2] = xim[slot(m + R / 2)];
+        re[m] = lds_ld(&xbuf[slot(m)]); re[m + R / 2] = lds_ld(&xbuf[slot(m + R / 2)]);
+        im[m] = lds_ld(&xim[slot(m)]);  im[m + R / 2] = lds_ld(&xim[slot(m + R / 2)]);
     }
 }
 
@@ -336,7 +370,7 @@ __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double
     exchange<LOGN, 1, 2, DUAL>(re, im, xbuf, lane, xim);
     P12<R, G::LR - 1>::fwd(re, im, w2.w);
 }
-template <int LOGN, bool DUAL = false>
+template <int LOGN, bool DUAL = false, bool TRIV = false>
 __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                               const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
                                               double* __restrict__ xim = nullptr) {
@@ -344,7 +378,7 @@ __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double
     Tw<G::NLOW - 4> w3;
     w3.load(tw + G::TW_P3, 1);
     exchange<LOGN, 2, 3, DUAL>(re, im, xbuf, lane, xim);
-    P3<G::R, G::NLOW, G::LOW - 1>::fwd(re, im, w3.w);
+    P3<G::R, G::NLOW, G::LOW - 1, TRIV>::fwd(re, im, w3.w);
 }
 template <int LOGN, bool DUAL = false>
 __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
@@ -397,14 +431,14 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
         exchange<LOGN, 2, 3, true>(re[j], im[j], xbuf, lane, xim);
     }
 }
-template <int LOGN, int NR>
+template <int LOGN, int NR, bool TRIV = false>
 __device__ __forceinline__ void fft_forward_multi_b(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
                                                     const cplx* __restrict__ tw) {
     typedef Geo<LOGN> G;
     Tw<G::NLOW - 4> w3;
     w3.load(tw + G::TW_P3, 1);
 #pragma unroll
-    for (int j = 0; j < NR; j++) P3<G::R, G::NLOW, G::LOW - 1>::fwd(re[j], im[j], w3.w);
+    for (int j = 0; j < NR; j++) P3<G::R, G::NLOW, G::LOW - 1, TRIV>::fwd(re[j], im[j], w3.w);
 }
 
 // The forward transform cut at its first exchange, for two waves: head = twist, pass 1, write half of the exchange (into
@@ -443,7 +477,7 @@ __device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], dou
 // coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
 // tw_small holds the pass-2/3 entries (always LDS), tw_big the pass-1 and untwist entries (LDS, or -- where the LDS
 // budget is better spent on resident gates, N = 2048 -- the global table; both pointers use the per-direction offsets).
-template <int LOGN, bool DUAL = false>
+template <int LOGN, bool DUAL = false, bool TRIV = false>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                             const cplx* __restrict__ tw_small, const cplx* __restrict__ tw_big,
                                             double* __restrict__ xbuf, int lane, double* __restrict__ xim = nullptr) {
@@ -451,7 +485,7 @@ __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (
     constexpr int R = G::R;
     Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1; Tw<R> wt;
     w3.load(tw_small + G::TW_P3, 1);
-    P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
+    P3<R, G::NLOW, G::LOW - 1, TRIV>::template inv<false>(re, im, w3.w);
     w2.load(tw_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
     exchange<LOGN, 3, 2, DUAL>(re, im, xbuf, lane, xim);
     P12<R, G::LR - 1>::inv(re, im, w2.w);

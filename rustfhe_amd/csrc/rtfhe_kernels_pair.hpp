@@ -41,6 +41,10 @@
 #ifndef PAIR_RAISE_AT
 #define PAIR_RAISE_AT 8
 #endif
+// the pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies (fwd_stage_tw, TRIV0); A/B: -DPAIR_TRIV=false
+#ifndef PAIR_TRIV
+#define PAIR_TRIV true
+#endif
 
 namespace rtfhe {
 
@@ -52,6 +56,18 @@ __device__ __forceinline__ void lds_barrier() {
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+}
+
+// the first row of a fold: the reference adds it to FrrSeries::zero() (trgsw.rs:290-299); +0.0 + x == x for every x except that
+// it turns a -0.0 into +0.0, and the sign of a zero never reaches a torus word (see fwd_stage_tw in rtfhe_device.hpp)
+template <int R>
+__device__ __forceinline__ void mac_row_first(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const double ii = b[m].y * im[m], rr = b[m].x * re[m], ri = b[m].x * im[m], ir = b[m].y * re[m];
+        sre[m] = rr - ii;
+        sim[m] = ir + ri;
+    }
 }
 
 template <int R>
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         fft_forward_multi_a<LOGN, L>(xr, xi, twf, myx, myx + G::XSLOTS, ln);
         prio_point(2);
         PAIR_STAMP(1);
-        fft_forward_multi_b<LOGN, L>(xr, xi, twf);
+        fft_forward_multi_b<LOGN, L, PAIR_TRIV>(xr, xi, twf);
         prio_point(5);
         PAIR_STAMP(3);
 #endif
@@ -249,8 +265,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 
         // slot P (side 0): component 0 over rows 0..2 from +0.0
         if (side == 0) {
+#ifdef PAIR_ZERO_FOLD
             zero();
             mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
+#else
+            mac_row_first<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
+#endif
             mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, i, 3);
             mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, i, 4);
             put(hand0);
@@ -262,6 +282,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
         // on top of side 0's partial sum -> hand0
+        // (the same code for both sides, see the header: side 0's fold keeps its explicit +0.0 start here -- a side-dependent
+        // first row made the allocator spill 60 VGPRs)
         if (side == 0) zero(); else get(hand0);
         mac_row<R>(sre, sim, bA, xr[0], xi[0]); fetch(bA, i, side ? 2 : 5);
         mac_row<R>(sre, sim, bB, xr[1], xi[1]); fetch(bB, side ? i : nxt, side ? 3 : 0);
@@ -284,7 +306,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         PAIR_STAMP(8);
 
         // the 2/N input scaling of the reference (fft_processor_spqlios.cpp:158) is folded into the untwist twiddles
-        fft_inverse<LOGN, true>(sre, sim, twi, twi, myx, lane);
+        fft_inverse<LOGN, true, PAIR_TRIV>(sre, sim, twi, twi, myx, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
