@@ -52,7 +52,41 @@ impl<const TLWE_N: usize, const TRLWE_N: usize> TFHE<TLWE_N, TRLWE_N> {
             });
             Self::check(std::ptr::null(), sys::rtfhe_ctx_create(&p, device as c_int, &mut ctx));
             Self::check(ctx, sys::rtfhe_load_bk_torus(ctx, bk.as_ptr()));
-            Self::check(ctx, sys::rtfhe_load_ksk(ctx, ksk.as_ptr()));
+            // in through the reference's own container shape [[TLWERep; IKS_T = 4]; IKS_L = 8] (tlwe.rs:243-245), entry t = 4 included
+            let mut ksk_ref = vec![0u32; TRLWE_N * p.ks_t as usize * (1usize << p.ks_basebit) * (TLWE_N + 1)];
+            Self::check(std::ptr::null(), match key_seed {
+                None => sys::rtfhe_ksk_expand_ref(&p, k0.as_ptr(), k1.as_ptr(), ksk.as_ptr(), ksk_ref.as_mut_ptr()),
+                Some(seed) => sys::rtfhe_ksk_expand_ref_deterministic(&p, seed ^ 0x4b534b, k0.as_ptr(), k1.as_ptr(), ksk.as_ptr(), ksk_ref.as_mut_ptr()),
+            });
+            Self::check(ctx, sys::rtfhe_load_ksk_ref(ctx, ksk_ref.as_ptr()));
+        }
+        TFHE { ctx, params: p }
+    }
+    /// For keys the reference crate has ALREADY generated: `bk_f` = `BootstrappingKey(Vec<TRGSWRepF>)` flattened to
+    /// `f64[n][2][6][N]` (per TRGSW `cipher_f[0..6]` then `pkey_f[0..6]`, tfhe.rs:116, trgsw.rs:64-67) and `ksk` = the inner Vec of
+    /// `KeySwitchingKey(Vec<[[TLWERep<M>; IKS_T]; IKS_L]>)` exactly as it is, 4 entries per level (tlwe.rs:178-180, 243-245).
+    /// Every `TLWERep` is written a[0..n) then b (its Rust field order is not `repr(C)`), level by level, entry by entry.
+    pub fn from_reference_keys(bk_f: &[f64], ksk: &[[[TLWERep<TLWE_N>; 4]; 8]], device: i32) -> Self {
+        let mut p = sys::rtfhe_params { n: 0, N: 0, nbit: 0, l: 0, bgbit: 0, ks_t: 0, ks_basebit: 0 };
+        unsafe { sys::rtfhe_default_params(&mut p) };
+        p.n = TLWE_N as i32; p.N = TRLWE_N as i32; p.nbit = (TRLWE_N as u32).trailing_zeros() as i32;
+        assert_eq!(ksk.len(), TRLWE_N);
+        assert_eq!(bk_f.len(), TLWE_N * 2 * 2 * p.l as usize * TRLWE_N);
+        let w = TLWE_N + 1;
+        let mut flat = vec![0u32; TRLWE_N * 8 * 4 * w];
+        for (i, ks_i) in ksk.iter().enumerate() {
+            for (l, ks_i_l) in ks_i.iter().enumerate() {
+                for (t, rep) in ks_i_l.iter().enumerate() {
+                    let at = ((i * 8 + l) * 4 + t) * w;
+                    rep.write_flat(&mut flat[at..at + w]);
+                }
+            }
+        }
+        let mut ctx: *mut sys::rtfhe_ctx = std::ptr::null_mut();
+        unsafe {
+            Self::check(std::ptr::null(), sys::rtfhe_ctx_create(&p, device as c_int, &mut ctx));
+            Self::check(ctx, sys::rtfhe_load_bk_fft(ctx, bk_f.as_ptr()));
+            Self::check(ctx, sys::rtfhe_load_ksk_ref(ctx, flat.as_ptr()));
         }
         TFHE { ctx, params: p }
     }

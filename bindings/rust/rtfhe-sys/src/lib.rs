@@ -39,6 +39,7 @@ extern "C" {
     pub fn rtfhe_ctx_create(p: *const rtfhe_params, device_id: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
     pub fn rtfhe_ctx_create_multi(p: *const rtfhe_params, device_ids: *const c_int, n_dev: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
     pub fn rtfhe_ctx_device_count(ctx: *const rtfhe_ctx) -> c_int;
+    pub fn rtfhe_shard_range(count: usize, d: c_int, n_dev: c_int, begin: *mut usize, end: *mut usize) -> c_int;
     pub fn rtfhe_host_alloc(bytes: usize) -> *mut c_void;
     pub fn rtfhe_host_free(p: *mut c_void);
     pub fn rtfhe_ctx_destroy(ctx: *mut rtfhe_ctx);
@@ -54,6 +55,8 @@ extern "C" {
     pub fn rtfhe_load_bk_fft(ctx: *mut rtfhe_ctx, bk_f: *const f64) -> c_int;
     pub fn rtfhe_export_bk_fft(ctx: *mut rtfhe_ctx, bk_f: *mut f64) -> c_int;
     pub fn rtfhe_load_ksk(ctx: *mut rtfhe_ctx, ksk: *const u32) -> c_int;
+    /// `KeySwitchingKey(Vec<[[TLWERep<M>; IKS_T]; IKS_L]>)` flattened as it stands: `u32[N][8][4][n+1]` (tlwe.rs:243-245)
+    pub fn rtfhe_load_ksk_ref(ctx: *mut rtfhe_ctx, ksk_ref: *const u32) -> c_int;
 
     pub fn rtfhe_gate_batch(ctx: *mut rtfhe_ctx, op: c_int, in0: *const u32, in1: *const u32, out: *mut u32, count: usize) -> c_int;
     pub fn rtfhe_mux_batch(ctx: *mut rtfhe_ctx, c: *const u32, in0: *const u32, in1: *const u32, out: *mut u32, count: usize) -> c_int;
@@ -85,6 +88,8 @@ extern "C" {
     pub fn rtfhe_keygen_with_keys(p: *const rtfhe_params, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
     pub fn rtfhe_tlwe_encrypt_bits(p: *const rtfhe_params, key0: *const i32, bits: *const u8, out: *mut u32, count: usize) -> c_int;
     // TEST ONLY (seeded xoshiro256**, not secure)
+    pub fn rtfhe_ksk_expand_ref(p: *const rtfhe_params, key0: *const i32, key1: *const i32, ksk: *const u32, ksk_ref: *mut u32) -> c_int;
+    pub fn rtfhe_ksk_expand_ref_deterministic(p: *const rtfhe_params, seed: u64, key0: *const i32, key1: *const i32, ksk: *const u32, ksk_ref: *mut u32) -> c_int;
     pub fn rtfhe_keygen_deterministic(p: *const rtfhe_params, seed: u64, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;
     pub fn rtfhe_keygen_with_keys_deterministic(p: *const rtfhe_params, seed: u64, key0: *const i32, key1: *const i32, bk: *mut u32, ksk: *mut u32) -> c_int;
     pub fn rtfhe_tlwe_encrypt_bits_deterministic(p: *const rtfhe_params, key0: *const i32, seed: u64, bits: *const u8, out: *mut u32, count: usize) -> c_int;

@@ -11,7 +11,11 @@
  *   rtfhe_load_bk_torus              <- BootstrappingKey::new's TRGSWRepF::from (hom_nand/src/tfhe.rs:119-126,
  *                                       hom_nand/src/trgsw.rs:68-76)
  *   rtfhe_load_bk_fft                <- BootstrappingKey(Vec<TRGSWRepF>) as the reference holds it (tfhe.rs:116)
- *   rtfhe_load_ksk                   <- KeySwitchingKey(Vec<[[TLWERep;3];8]>) (hom_nand/src/tlwe.rs:243-245)
+ *   rtfhe_load_ksk_ref               <- KeySwitchingKey(Vec<[[TLWERep<M>; IKS_T]; IKS_L]>) = [[TLWERep; 4]; 8] per coefficient, exactly as
+ *                                       the reference holds it (hom_nand/src/tlwe.rs:178-180, 243-245): entry [i][l][t-1] = get(i, l, t),
+ *                                       t = 1 .. 4 (:252-283)
+ *   rtfhe_load_ksk                   <- the same key without the entry t = 4 of every level, which identity_key_switch never reads
+ *                                       (its digits are basebit = 2 bits wide, tlwe.rs:43-73): [[TLWERep; 3]; 8]
  *   rtfhe_gate_batch[_dev]           <- TFHE::hom_nand/and/or/xor/not (hom_nand/src/tfhe.rs:41-71), count gates at once
  *   rtfhe_mux_batch                  <- TFHE::hom_mux (tfhe.rs:27-40)
  *   rtfhe_circuit_wave_dev           <- eval_logic_expr over impl Logip for TFHE (nander/src/lib.rs:40-89), one level at a time
@@ -43,7 +47,9 @@
  *   BK torus    u32[n][2][2l][N]   comp 0 = TRGSWRep.cipher rows, comp 1 = TRGSWRep.p_key rows
  *   BK fft      f64[n][2][2l][N]   same order; each poly an FrrSeries: Re[0..N/2) then Im[0..N/2),
  *                                  in the transform's native order (utils/src/spqlios.rs:147,205-208)
- *   KSK         u32[N][t][base-1][n+1]
+ *   KSK         u32[N][t][base-1][n+1]   rows d = 1 .. base-1 of level l of coefficient i   (rtfhe_load_ksk, rtfhe_keygen*)
+ *   KSK (ref)   u32[N][t][base][n+1]     the reference's [[TLWERep; IKS_T]; IKS_L]: one more row (t = base) per level, never read
+ *                                        (rtfhe_load_ksk_ref drops it)
  */
 #ifndef RTFHE_H
 #define RTFHE_H
@@ -101,9 +107,12 @@ int rtfhe_ctx_create(const rtfhe_params *p, int device_id, rtfhe_ctx **out);
  * device and are bit-identical.  *_dev and stage-level calls run on the primary device only. */
 int rtfhe_ctx_create_multi(const rtfhe_params *p, const int *device_ids, int n_dev, rtfhe_ctx **out);
 int rtfhe_ctx_device_count(const rtfhe_ctx *ctx);      /* devices behind this context (1 for rtfhe_ctx_create) */
+/* the range [*begin, *end) of a `count`-gate host batch that entry d of an n_dev-device context bootstraps (no GPU needed) */
+int rtfhe_shard_range(size_t count, int d, int n_dev, size_t *begin, size_t *end);
 void rtfhe_ctx_destroy(rtfhe_ctx *ctx);
-/* pinned host memory for ciphertext buffers: host-pointer calls DMA straight from / into such a buffer; any other host
- * pointer is staged through the context's own pinned buffers (one extra host copy) */
+/* pinned host memory for ciphertext buffers: host-pointer calls DMA straight from / into such a buffer.  Any other host
+ * pointer is handed to the runtime's own pageable-copy path (measured faster than staging it here); RTFHE_STAGING=1 in the
+ * environment stages pageable buffers through the context's pinned buffers instead (one extra host copy). */
 void *rtfhe_host_alloc(size_t bytes);
 void rtfhe_host_free(void *p);
 const char *rtfhe_last_error(const rtfhe_ctx *ctx);   /* ctx may be NULL: last ctx-less error */
@@ -121,6 +130,8 @@ int rtfhe_load_bk_torus(rtfhe_ctx *ctx, const uint32_t *bk /* [n][2][2l][N] */);
 int rtfhe_load_bk_fft(rtfhe_ctx *ctx, const double *bk_f /* [n][2][2l][N] */);
 int rtfhe_export_bk_fft(rtfhe_ctx *ctx, double *bk_f /* [n][2][2l][N] */);
 int rtfhe_load_ksk(rtfhe_ctx *ctx, const uint32_t *ksk /* [N][t][base-1][n+1] */);
+/* the reference's container flattened as it stands: [N][IKS_L = t][IKS_T = base][n+1], each TLWERep as a[0..n) then b */
+int rtfhe_load_ksk_ref(rtfhe_ctx *ctx, const uint32_t *ksk_ref /* [N][t][base][n+1] */);
 
 /* ---- the hot path: host buffers ---- */
 int rtfhe_gate_batch(rtfhe_ctx *ctx, int op, const uint32_t *in0, const uint32_t *in1,
@@ -142,8 +153,9 @@ int rtfhe_circuit_wave_dev(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0
 /* A whole levelised netlist as ONE submission (BASELINE config 4; the reference walks its expression tree gate by gate,
  * nander/src/lib.rs:72-89): the waves wave_offsets[w] .. wave_offsets[w+1] (host array, num_waves + 1 entries) of the same four
  * device arrays are captured once into a HIP graph; rtfhe_circuit_launch replays it on `stream` (asynchronous, one runtime
- * call per evaluation).  The device arrays and the wire table must stay alive and in place while the circuit exists, and a circuit
- * must be destroyed before the context it was created on. */
+ * call per evaluation).  The device arrays and the wire table must stay alive and in place while the circuit exists.  A circuit
+ * is normally destroyed before its context; if the context goes first, the circuit's graph is released with it, a later
+ * rtfhe_circuit_launch fails with RTFHE_ERR_STATE and rtfhe_circuit_destroy only frees the handle. */
 typedef struct rtfhe_circuit rtfhe_circuit;
 int rtfhe_circuit_create(rtfhe_ctx *ctx, const void *d_ops, const void *d_idx0, const void *d_idx1, const void *d_idx_out,
                          const int32_t *wave_offsets, int32_t num_waves, void *d_wires, size_t num_wires, rtfhe_circuit **out);
@@ -179,12 +191,18 @@ int rtfhe_keygen(const rtfhe_params *p, int32_t *key0 /* [n] */, int32_t *key1 /
 int rtfhe_keygen_with_keys(const rtfhe_params *p, const int32_t *key0, const int32_t *key1, uint32_t *bk, uint32_t *ksk);
 int rtfhe_tlwe_encrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint8_t *bits, uint32_t *out /* [count][n+1] */,
                             size_t count);
+/* the reference's KeySwitchingKey shape from the compact one: entries t = 1 .. base-1 of every level copied, entry t = base =
+ * TLWE(base * s_i / 2^(basebit (l+1))) freshly encrypted as KeySwitchingKey::new fills it (hom_nand/src/tlwe.rs:252-274) */
+int rtfhe_ksk_expand_ref(const rtfhe_params *p, const int32_t *key0, const int32_t *key1,
+                         const uint32_t *ksk /* [N][t][base-1][n+1] */, uint32_t *ksk_ref /* [N][t][base][n+1] */);
 /* TEST ONLY -- NOT SECURE: the same, reproducible from a 64-bit seed expanded through xoshiro256** (not a CSPRNG: whoever knows
  * the seed regenerates every mask and noise sample and recovers the secret key from the key-switching key; a reused seed
  * reuses mask and noise).  For fixtures, parity tests and benchmarks only; never for keys or ciphertexts that protect data. */
 int rtfhe_keygen_deterministic(const rtfhe_params *p, uint64_t seed, int32_t *key0, int32_t *key1, uint32_t *bk, uint32_t *ksk);
 int rtfhe_keygen_with_keys_deterministic(const rtfhe_params *p, uint64_t seed, const int32_t *key0, const int32_t *key1,
                                          uint32_t *bk, uint32_t *ksk);
+int rtfhe_ksk_expand_ref_deterministic(const rtfhe_params *p, uint64_t seed, const int32_t *key0, const int32_t *key1,
+                                       const uint32_t *ksk, uint32_t *ksk_ref);
 int rtfhe_tlwe_encrypt_bits_deterministic(const rtfhe_params *p, const int32_t *key0, uint64_t seed,
                                           const uint8_t *bits, uint32_t *out /* [count][n+1] */, size_t count);
 int rtfhe_tlwe_decrypt_bits(const rtfhe_params *p, const int32_t *key0, const uint32_t *in,

@@ -500,6 +500,29 @@ void orc_key_switch(const orc_params *p, const uint32_t *ksk, const uint32_t *tl
     }
 }
 
+/* The same key switch reading the key in the reference's OWN container shape, KeySwitchingKey(Vec<[[TLWERep<M>; IKS_T]; IKS_L]>)
+ * with IKS_T = 2^IKS_BASEBIT entries per level (hom_nand/src/tlwe.rs:178-180, 243-245): get(i, l, t) = [i][l][t - 1]
+ * (tlwe.rs:281-283), called with t = digit in 1 .. base-1 (tlwe.rs:43-73) -- entry [base - 1] of a level is never read. */
+void orc_key_switch_ref(const orc_params *p, const uint32_t *ksk_ref, const uint32_t *tlwe1, uint32_t *out) {
+    const int32_t N = p->N, n = p->n, t = p->ks_t, bb = p->ks_basebit;
+    const int32_t iks_t = 1 << bb;
+    const uint32_t total = 32;
+    const uint32_t round = ((total - (uint32_t)(t * bb)) != 0) ? (1u << (total - (uint32_t)(t * bb) - 1)) : 0u;
+    const uint32_t mask = (1u << bb) - 1;
+    for (int32_t k = 0; k < n; k++) out[k] = 0;
+    out[n] = tlwe1[N];
+    for (int32_t i = 0; i < N; i++) {
+        const uint32_t u = tlwe1[i] + round;
+        for (int32_t l = 0; l < t; l++) {
+            const uint32_t d = (u >> (total - (uint32_t)bb * (uint32_t)(l + 1))) & mask;
+            if (d != 0) {
+                const uint32_t *row = ksk_ref + (((size_t)i * t + l) * iks_t + (d - 1)) * (size_t)(n + 1);
+                for (int32_t k = 0; k <= n; k++) out[k] -= row[k];
+            }
+        }
+    }
+}
+
 void orc_gate_linear(const orc_params *p, int op, const uint32_t *in0, const uint32_t *in1, uint32_t *t) {
     const int32_t n = p->n;
     const uint32_t c8 = orc_torus_from_f32(1.0f / 8.0f), c4 = orc_torus_from_f32(2.0f * (1.0f / 8.0f));
@@ -716,6 +739,24 @@ void orc_ksk_gen(orc_rng *r, const orc_params *p, const int32_t *key1, const int
                 const uint32_t item = orc_torus_from_f32((float)key1[i] * pw * (float)(d + 1));
                 orc_tlwe_encrypt(r, n, key0, item, alpha, ksk + (((size_t)i * t + l) * base1 + d) * (size_t)(n + 1));
             }
+}
+
+/* KeySwitchingKey::new in the reference's shape (tlwe.rs:247-277): IKS_T = base entries per level, entry t - 1 =
+ * TLWE(t * s_i / 2^(basebit (l+1))), t = 1 .. base.  Entries 1 .. base-1 are taken from `ksk` (orc_ksk_gen, so that fixtures made
+ * with the compact key stay valid); entry `base` is encrypted here. */
+void orc_ksk_expand_ref(orc_rng *r, const orc_params *p, const int32_t *key1, const int32_t *key0, float alpha,
+                        const uint32_t *ksk, uint32_t *ksk_ref) {
+    const int32_t N = p->N, n = p->n, t = p->ks_t, bb = p->ks_basebit, base = 1 << bb;
+    const size_t w = (size_t)n + 1;
+    for (int32_t i = 0; i < N; i++)
+        for (int32_t l = 0; l < t; l++) {
+            const size_t il = (size_t)i * t + l;
+            memcpy(ksk_ref + il * base * w, ksk + il * (base - 1) * w, (size_t)(base - 1) * w * sizeof(uint32_t));
+            float pw = 1.0f;
+            for (int32_t e = 0; e < bb * (l + 1); e++) pw *= 0.5f;
+            const uint32_t item = orc_torus_from_f32((float)key1[i] * pw * (float)base);
+            orc_tlwe_encrypt(r, n, key0, item, alpha, ksk_ref + (il * base + (base - 1)) * w);
+        }
 }
 
 uint64_t orc_fnv64(const void *data, size_t bytes) {

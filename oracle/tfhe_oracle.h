@@ -112,6 +112,8 @@ void orc_blind_rotate(const orc_params *p, orc_plan *pl, const double *bk_f, con
 void orc_sample_extract(int32_t N, const uint32_t *trlwe, int32_t index, uint32_t *tlwe1 /* [N+1] */);
 /* TLWERep::identity_key_switch, tlwe.rs:43-73 */
 void orc_key_switch(const orc_params *p, const uint32_t *ksk, const uint32_t *tlwe1, uint32_t *out);
+/* the same, key in the reference's container shape u32[N][t][base][n+1] (tlwe.rs:243-245, get(i,l,t) = [i][l][t-1]) */
+void orc_key_switch_ref(const orc_params *p, const uint32_t *ksk_ref, const uint32_t *tlwe1, uint32_t *out);
 /* gate pre-steps, tfhe.rs:27-71 */
 void orc_gate_linear(const orc_params *p, int op, const uint32_t *in0, const uint32_t *in1, uint32_t *t);
 /* TFHE::bootstrap, tfhe.rs:73-88 */
@@ -155,6 +157,8 @@ void orc_bk_gen(orc_rng *r, orc_plan *pl, const orc_params *p, const int32_t *ke
 void orc_ksk_gen(orc_rng *r, const orc_params *p, const int32_t *key1, const int32_t *key0, float alpha,
                  uint32_t *ksk /* [N][t][base-1][n+1] */);
 
+void orc_ksk_expand_ref(orc_rng *r, const orc_params *p, const int32_t *key1, const int32_t *key0, float alpha,
+                        const uint32_t *ksk /* [N][t][base-1][n+1] */, uint32_t *ksk_ref /* [N][t][base][n+1] */);
 uint64_t orc_fnv64(const void *data, size_t bytes);
 
 #ifdef __cplusplus

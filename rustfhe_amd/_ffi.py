@@ -36,6 +36,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -
 _SIGNATURES = {
     "rtfhe_default_params": (None, ["PP"]),
     "rtfhe_ctx_create": (C.c_int, ["PP", C.c_int, C.POINTER(C.c_void_p)]),
+    "rtfhe_shard_range": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rtfhe_ctx_create_multi": (C.c_int, ["PP", C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "rtfhe_ctx_device_count": (C.c_int, [C.c_void_p]),
     "rtfhe_ctx_destroy": (None, [C.c_void_p]),
@@ -52,6 +53,7 @@ _SIGNATURES = {
     "rtfhe_load_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_export_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_load_ksk": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rtfhe_load_ksk_ref": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_gate_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_mux_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -75,6 +77,8 @@ _SIGNATURES = {
     "rtfhe_keygen": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_keygen_with_keys": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_ksk_expand_ref": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_ksk_expand_ref_deterministic": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_keygen_deterministic": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_keygen_with_keys_deterministic": (C.c_int, ["PP", C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_tlwe_encrypt_bits_deterministic": (C.c_int, ["PP", C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -10,13 +10,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtfhe_hip.so")
-SOURCES = ["rtfhe_api.hip", "rtfhe_keygen.cpp", "rtfhe_wire.cpp"]
+SOURCES = ["rtfhe_api.hip", "rtfhe_keygen.cpp", "rtfhe_wire.cpp", "rtfhe_spqlios.cpp"]
 
 
 def _deps():
     """Every source and header under csrc/ plus the public header: a changed header must rebuild the library."""
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp", ".h"))]
-    return files + [os.path.join(HERE, "..", "include", "rtfhe.h")]
+    return files + [os.path.join(HERE, "..", "include", "rtfhe.h"), os.path.join(HERE, "..", "include", "rtfhe_spqlios.h")]
 
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

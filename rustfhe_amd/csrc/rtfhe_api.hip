@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -202,6 +204,7 @@ struct HostTw {
 
 }  // namespace
 
+struct rtfhe_circuit;
 struct rtfhe_ctx {
     rtfhe_params p{};
     int device = 0;
@@ -234,6 +237,7 @@ struct rtfhe_ctx {
     // multi-device context (rtfhe_ctx_create_multi): one full single-device context per further device; `this` is device 0 of
     // the set.  Keys are loaded once on this context and copied device-to-device; host-pointer batches are sharded.
     std::vector<rtfhe_ctx*> peers;
+    std::vector<rtfhe_circuit*> circuits;   // live HIP-graph circuits of this context: orphaned (not freed) by rtfhe_ctx_destroy
     void* h_mux[2] = {nullptr, nullptr};   // device intermediates of rtfhe_mux_batch
     size_t cap_mux = 0;
     int num_cus = 256;
@@ -241,6 +245,24 @@ struct rtfhe_ctx {
     int wg_max = 512;      // RTFHE_WG_MAX_GATES: largest batch routed to the workgroup-per-gate kernel
     std::string err;
 };
+
+// a whole levelised netlist recorded into a HIP graph (rtfhe_circuit_create)
+struct rtfhe_circuit {
+    rtfhe_ctx* ctx = nullptr;  // null once the context has been destroyed (the handle then only remains to be freed)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int device = 0;            // kept here: the context may be destroyed before the circuit
+    int32_t waves = 0;
+    int64_t launches = 0;      // kernel launches one replay stands for
+};
+
+// releases the graph objects of a circuit (the handle itself stays valid for rtfhe_circuit_destroy)
+static void circuit_release(rtfhe_circuit* c) {
+    (void)hipSetDevice(c->device);
+    if (c->exec) (void)hipGraphExecDestroy(c->exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->exec = nullptr; c->graph = nullptr;
+}
 
 namespace {
 
@@ -273,22 +295,31 @@ int ensure(rtfhe_ctx* ctx, void** ptr, size_t* cap, size_t bytes) {
     return 0;
 }
 
-// The dynamic-LDS limit of a kernel is a per-device attribute: granted once (normally at context creation, see
-// prime_kernel_attributes) and remembered, so that a launch costs no runtime call beyond the launch itself.
+// The dynamic-LDS limit of a kernel is a per-function, per-DEVICE attribute shared by every context of the process: it is only
+// ever raised (a second context with a smaller mask would otherwise lower it under the first one's launches) and remembered
+// process-wide, so that a launch costs no runtime call beyond the launch itself.
+std::mutex g_lds_mutex;
+std::map<std::pair<int, const void*>, size_t> g_lds_granted;     // (device, kernel) -> largest dynamic LDS granted so far
+
 template <typename K>
 int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
     const void* key = reinterpret_cast<const void*>(kernel);
     auto it = ctx->lds_allowed.find(key);
-    if (it != ctx->lds_allowed.end() && it->second >= bytes) return 0;
-    const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
-        hipFuncAttributes fa{};
-        const hipError_t e2 = hipFuncGetAttributes(&fa, key);
-        return fail(ctx, RTFHE_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize = ") + std::to_string(bytes) + "): " + hipGetErrorString(e) +
-                    (e2 == hipSuccess ? " [kernel: static LDS " + std::to_string(fa.sharedSizeBytes) + ", regs " + std::to_string(fa.numRegs) +
-                                        ", max threads " + std::to_string(fa.maxThreadsPerBlock) + "]" : std::string(" [hipFuncGetAttributes: ") + hipGetErrorString(e2) + "]"));
+    if (it != ctx->lds_allowed.end() && it->second >= bytes) return 0;          // this context has already seen >= bytes granted
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    size_t& granted = g_lds_granted[std::make_pair(ctx->device, key)];
+    if (granted < bytes) {
+        const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            hipFuncAttributes fa{};
+            const hipError_t e2 = hipFuncGetAttributes(&fa, key);
+            return fail(ctx, RTFHE_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize = ") + std::to_string(bytes) + "): " + hipGetErrorString(e) +
+                        (e2 == hipSuccess ? " [kernel: static LDS " + std::to_string(fa.sharedSizeBytes) + ", regs " + std::to_string(fa.numRegs) +
+                                            ", max threads " + std::to_string(fa.maxThreadsPerBlock) + "]" : std::string(" [hipFuncGetAttributes: ") + hipGetErrorString(e2) + "]"));
+        }
+        granted = bytes;
     }
-    ctx->lds_allowed[key] = bytes;
+    ctx->lds_allowed[key] = granted;
     return 0;
 }
 
@@ -740,11 +771,21 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
 }
 
 // A *_dev entry point must never launch on a pointer the GPU cannot dereference (a host pointer passed by mistake would fault
-// the device): device, managed and pinned-host allocations pass, anything else is refused before the launch.
-bool gpu_accessible(const void* p) {
+// the device): memory of the context's own device, managed and pinned-host allocations pass, memory of another GPU only with peer
+// access, anything else is refused before the launch.
+bool gpu_accessible(const rtfhe_ctx* ctx, const void* p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeHost;
+    if (a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeHost) return true;
+    if (a.type != hipMemoryTypeDevice) return false;
+    if (a.device == ctx->device) return true;
+    // memory of ANOTHER GPU: only when this device has peer access to it (a kernel on ctx->device would otherwise fault on it)
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, ctx->device, a.device) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+    const hipError_t e = hipDeviceEnablePeerAccess(a.device, 0);          // current device = ctx->device (use())
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return false; }
+    (void)hipGetLastError();
+    return true;
 }
 
 // true when `p` is host memory the GPU can DMA from directly (hipHostMalloc / hipHostRegister, e.g. rtfhe_host_alloc)
@@ -886,9 +927,13 @@ int rtfhe_ctx_create_multi(const rtfhe_params* p, const int* device_ids, int n_d
     if (!p || !out || !device_ids) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
     *out = nullptr;
     if (n_dev < 1 || n_dev > 64) return fail(nullptr, RTFHE_ERR_INVALID, "n_dev out of range");
-    for (int a = 0; a < n_dev; a++)
-        for (int b = a + 1; b < n_dev; b++)
-            if (device_ids[a] == device_ids[b]) return fail(nullptr, RTFHE_ERR_INVALID, "device_ids must be distinct");
+    // TEST ONLY: RTFHE_TEST_ALLOW_DUP_DEVICES=1 lets one GPU appear several times, so that the multi-device paths (per-device host
+    // threads, device-to-device key replication, shard offsets, error aggregation) run on a one-GPU box
+    const char* dup = std::getenv("RTFHE_TEST_ALLOW_DUP_DEVICES");
+    if (!(dup && std::atoi(dup) != 0))
+        for (int a = 0; a < n_dev; a++)
+            for (int b = a + 1; b < n_dev; b++)
+                if (device_ids[a] == device_ids[b]) return fail(nullptr, RTFHE_ERR_INVALID, "device_ids must be distinct");
     rtfhe_ctx* ctx = nullptr;
     if (int rc = create_single(p, device_ids[0], &ctx)) return rc;
     for (int d = 1; d < n_dev; d++) {
@@ -902,6 +947,15 @@ int rtfhe_ctx_create_multi(const rtfhe_params* p, const int* device_ids, int n_d
 }
 
 int rtfhe_ctx_device_count(const rtfhe_ctx* ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
+// the contiguous gate range entry d of an n_dev-device context takes of a host batch of `count` gates (pure arithmetic: what
+// run_host_bootstrap / rtfhe_mux_batch use, exported so that a caller can lay out per-device buffers; no GPU needed)
+int rtfhe_shard_range(size_t count, int d, int n_dev, size_t* begin, size_t* end) {
+    if (n_dev < 1 || n_dev > 64 || d < 0 || d >= n_dev || !begin || !end) return fail(nullptr, RTFHE_ERR_INVALID, "rtfhe_shard_range: bad argument");
+    *begin = shard_begin(count, d, n_dev);
+    *end = shard_begin(count, d + 1, n_dev);
+    return 0;
+}
 
 // pinned host memory for ciphertext buffers: host-pointer calls DMA straight from / into it (no staging copy)
 void* rtfhe_host_alloc(size_t bytes) {
@@ -924,6 +978,10 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    // circuits that outlive their context: their graphs go now, the handles stay valid for rtfhe_circuit_destroy (which then
+    // only frees them) and rtfhe_circuit_launch (which then fails with RTFHE_ERR_STATE)
+    for (rtfhe_circuit* c : ctx->circuits) { circuit_release(c); c->ctx = nullptr; }
+    ctx->circuits.clear();
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->d_bk) (void)hipFree(ctx->d_bk);
@@ -1062,11 +1120,26 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
     return 0;
 }
 
+// The reference's own container shape: KeySwitchingKey(Vec<[[TLWERep<M>; IKS_T]; IKS_L]>) with IKS_T = 2^IKS_BASEBIT = 4 entries per
+// level (hom_nand/src/tlwe.rs:178-180, 243-245); entry t - 1 holds TLWE(t * s_i / 2^(basebit (l+1))) for t = 1 .. 4 (:252-274) and
+// get(i, l, t) reads [i][l][t - 1] (:281-283).  identity_key_switch only ever asks for t = digit in 1 .. 3 (:43-73: a basebit-wide
+// digit), so the 4th entry of every level is never read: it is dropped here and the rest goes through rtfhe_load_ksk.
+int rtfhe_load_ksk_ref(rtfhe_ctx* ctx, const uint32_t* ksk_ref) {
+    if (int rc = use(ctx)) return rc;
+    if (!ksk_ref) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    const size_t w = (size_t)ctx->p.n + 1, base = (size_t)1 << ctx->p.ks_basebit, levels = (size_t)ctx->p.N * ctx->p.ks_t;
+    std::vector<uint32_t> compact;
+    try { compact.resize(levels * (base - 1) * w); } catch (const std::bad_alloc&) { return fail(ctx, RTFHE_ERR_NOMEM, "host staging for the key-switching key"); }
+    for (size_t il = 0; il < levels; il++)
+        std::memcpy(compact.data() + il * (base - 1) * w, ksk_ref + il * base * w, (base - 1) * w * sizeof(uint32_t));
+    return rtfhe_load_ksk(ctx, compact.data());
+}
+
 int rtfhe_gate_batch_dev(rtfhe_ctx* ctx, int op, const void* d_in0, const void* d_in1, void* d_out, size_t count, void* stream) {
     if (int rc = use(ctx)) return rc;
     if (op < RTFHE_NAND || op > RTFHE_ANDNY) return fail(ctx, RTFHE_ERR_INVALID, "unknown gate");
     if (!d_in0 || !d_out) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
-    if (!gpu_accessible(d_in0) || (d_in1 && !gpu_accessible(d_in1)) || !gpu_accessible(d_out))
+    if (!gpu_accessible(ctx, d_in0) || (d_in1 && !gpu_accessible(ctx, d_in1)) || !gpu_accessible(ctx, d_out))
         return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_gate_batch_dev needs device pointers (got memory the GPU cannot address)");
     return launch_bootstrap(ctx, op, MODE_GATE, ctx->p.n, d_in0, d_in1, d_out, count, (hipStream_t)stream);
 }
@@ -1076,7 +1149,7 @@ int rtfhe_circuit_wave_dev(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0
     if (int rc = use(ctx)) return rc;
     if (!d_ops || !d_idx0 || !d_idx1 || !d_idx_out || !d_wires) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
     if (num_wires == 0 || num_wires > 0x7fffffff) return fail(ctx, RTFHE_ERR_INVALID, "num_wires out of range");
-    if (!gpu_accessible(d_ops) || !gpu_accessible(d_idx0) || !gpu_accessible(d_idx1) || !gpu_accessible(d_idx_out) || !gpu_accessible(d_wires))
+    if (!gpu_accessible(ctx, d_ops) || !gpu_accessible(ctx, d_idx0) || !gpu_accessible(ctx, d_idx1) || !gpu_accessible(ctx, d_idx_out) || !gpu_accessible(ctx, d_wires))
         return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_wave_dev needs device pointers (got memory the GPU cannot address)");
     return launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, count, (hipStream_t)stream,
                             (const int32_t*)d_ops, (const int32_t*)d_idx0, (const int32_t*)d_idx1, (const int32_t*)d_idx_out,
@@ -1084,14 +1157,6 @@ int rtfhe_circuit_wave_dev(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0
 }
 
 // ---- a whole levelised netlist as ONE submission: its dependency waves captured once into a HIP graph, replayed per run ----
-struct rtfhe_circuit {
-    rtfhe_ctx* ctx = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    int32_t waves = 0;
-    int64_t launches = 0;      // kernel launches one replay stands for
-};
-
 int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, const void* d_idx1, const void* d_idx_out,
                          const int32_t* wave_offsets, int32_t num_waves, void* d_wires, size_t num_wires, rtfhe_circuit** out) {
     if (int rc = use(ctx)) return rc;
@@ -1102,13 +1167,13 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
     for (int32_t w = 0; w < num_waves; w++)
         if (wave_offsets[w] < 0 || wave_offsets[w + 1] <= wave_offsets[w]) return fail(ctx, RTFHE_ERR_INVALID, "wave_offsets must be strictly increasing from >= 0");
     if (!ctx->has_bk || !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "keys not loaded");
-    if (!gpu_accessible(d_ops) || !gpu_accessible(d_idx0) || !gpu_accessible(d_idx1) || !gpu_accessible(d_idx_out) || !gpu_accessible(d_wires))
+    if (!gpu_accessible(ctx, d_ops) || !gpu_accessible(ctx, d_idx0) || !gpu_accessible(ctx, d_idx1) || !gpu_accessible(ctx, d_idx_out) || !gpu_accessible(ctx, d_wires))
         return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_create needs device pointers (got memory the GPU cannot address)");
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT)
         if (int rc = ntt_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
     rtfhe_circuit* c = new (std::nothrow) rtfhe_circuit();
     if (!c) return fail(ctx, RTFHE_ERR_NOMEM, "out of host memory");
-    c->ctx = ctx; c->waves = num_waves;
+    c->ctx = ctx; c->device = ctx->device; c->waves = num_waves;
     const int64_t before = ctx->launches;
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
@@ -1127,12 +1192,14 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
     if (e != hipSuccess) { delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
     e = hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGraphDestroy(c->graph); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    ctx->circuits.push_back(c);
     *out = c;
     return 0;
 }
 
 int rtfhe_circuit_launch(rtfhe_circuit* c, void* stream) {
-    if (!c || !c->ctx) return fail(nullptr, RTFHE_ERR_INVALID, "null circuit");
+    if (!c) return fail(nullptr, RTFHE_ERR_INVALID, "null circuit");
+    if (!c->ctx) return fail(nullptr, RTFHE_ERR_STATE, "the circuit's context has been destroyed");
     rtfhe_ctx* ctx = c->ctx;
     if (int rc = use(ctx)) return rc;
     HIPCHECK(ctx, hipGraphLaunch(c->exec, (hipStream_t)stream));
@@ -1142,9 +1209,11 @@ int rtfhe_circuit_launch(rtfhe_circuit* c, void* stream) {
 
 void rtfhe_circuit_destroy(rtfhe_circuit* c) {
     if (!c) return;
-    if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->exec) (void)hipGraphExecDestroy(c->exec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
+    if (c->ctx) {      // still attached: unregister (a context destroyed first has already released the graph and detached us)
+        auto& v = c->ctx->circuits;
+        for (size_t i = 0; i < v.size(); i++) if (v[i] == c) { v.erase(v.begin() + i); break; }
+        circuit_release(c);
+    }
     delete c;
 }
 

@@ -100,7 +100,7 @@ struct Tw {
 
 // DIF, twiddled: x0' = x0 + x1 ; x1' = (x0 - x1) * w      (spqlios-fft-impl.cpp:546-569)
 // TRIV0: the caller vouches that w[0] is exactly (1.0, +0.0) -- true of every table the reference builders produce for a
-// stage's first entry, cos(0) / sin(0); the host refuses any other table (check_trivial_twiddles, rtfhe_api.hip) -- and the
+// stage's first entry, cos(0) / sin(0) (a build that turns it on must refuse any other table in rtfhe_set_twiddles) -- and the
 // butterfly with q = 0 then skips its six multiply / add instructions: d * 1.0 == d and d - e * 0.0 == d for every finite d, e
 // EXCEPT in the sign of a zero result.  The sign of a zero never reaches a torus word: zero + x == x, zero * w is a zero, there
 // is no division or comparison on the path and Torus32(int64_t(+-0.0)) == 0.  Only kernels whose outputs are torus words use it;

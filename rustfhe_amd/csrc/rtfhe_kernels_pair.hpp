@@ -41,9 +41,12 @@
 #ifndef PAIR_RAISE_AT
 #define PAIR_RAISE_AT 8
 #endif
-// the pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies (fwd_stage_tw, TRIV0); A/B: -DPAIR_TRIV=false
+// A/B only (-DPAIR_TRIV=true -DPAIR_FIRST_ROW): the pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies
+// (fwd_stage_tw, TRIV0) and slot P's first row without its "+0.0 +".  64 fewer FP64 instructions per CMUX, same torus words --
+// and no faster (7.122 vs 7.122 ms per 1024 gates, profiles/r03/pair_lds_unpaired_reads_writes_ab.log): the kernel is not
+// bound by the FP64 instruction count alone.  Off by default: the shipped kernel executes the reference's operation list as is.
 #ifndef PAIR_TRIV
-#define PAIR_TRIV true
+#define PAIR_TRIV false
 #endif
 
 namespace rtfhe {
@@ -265,11 +268,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 
         // slot P (side 0): component 0 over rows 0..2 from +0.0
         if (side == 0) {
-#ifdef PAIR_ZERO_FOLD
+#ifdef PAIR_FIRST_ROW
+            mac_row_first<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
+#else
             zero();
             mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
-#else
-            mac_row_first<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
 #endif
             mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, i, 3);
             mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, i, 4);

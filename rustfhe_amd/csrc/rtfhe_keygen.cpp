@@ -204,6 +204,31 @@ int keygen_material(const rtfhe_params* p, const Source& src, const int32_t* key
     return 0;
 }
 
+// The reference's container shape from the compact one: [N][t][base][n+1] with entries 0 .. base-2 of every level copied and entry
+// base-1 = TLWE(base * s_i / 2^(basebit (l+1))) freshly encrypted, as KeySwitchingKey::new fills it (hom_nand/src/tlwe.rs:252-274).
+int ksk_expand_ref(const rtfhe_params* p, const Source& src, const int32_t* key0, const int32_t* key1, const uint32_t* ksk, uint32_t* ksk_ref) {
+    const int n = p->n, N = p->N, t = p->ks_t, bb = p->ks_basebit, base = 1 << bb;
+    for (int i = 0; i < n; i++) if (key0[i] != 0 && key0[i] != 1) return RTFHE_ERR_INVALID;
+    for (int i = 0; i < N; i++) if (key1[i] != 0 && key1[i] != 1) return RTFHE_ERR_INVALID;
+    const size_t w = (size_t)n + 1;
+    const float alpha_ks = 1.0f / 32768.0f;
+    for (int i = 0; i < N; i++) {
+        auto body = [&](Rng& r) {
+            for (int lv = 0; lv < t; lv++) {
+                const size_t il = (size_t)i * t + lv;
+                std::memcpy(ksk_ref + il * base * w, ksk + il * (base - 1) * w, (size_t)(base - 1) * w * sizeof(uint32_t));
+                float pw = 1.0f;
+                for (int e = 0; e < bb * (lv + 1); e++) pw *= 0.5f;
+                const uint32_t item = torus_from_f32((float)key1[i] * pw * (float)base);
+                tlwe_encrypt(r, n, key0, item, alpha_ks, ksk_ref + (il * base + (base - 1)) * w);
+            }
+        };
+        if (src.secure) { ChaCha r(src.key, ((uint64_t)3 << 32) | (uint32_t)i); body(r); }
+        else { Xoshiro r(src.seed + 0x94d049bb133111ebull * (uint64_t)(i + 1)); body(r); }
+    }
+    return 0;
+}
+
 int encrypt_bits(const rtfhe_params* p, Rng& r, const int32_t* key0, const uint8_t* bits, uint32_t* out, size_t count) {
     for (size_t g = 0; g < count; g++)
         tlwe_encrypt(r, p->n, key0, torus_from_f32(bits[g] ? 0.125f : -0.125f), 1.0f / 32768.0f, out + g * ((size_t)p->n + 1));
@@ -242,7 +267,19 @@ int rtfhe_tlwe_encrypt_bits(const rtfhe_params* p, const int32_t* key0, const ui
     return encrypt_bits(p, r, key0, bits, out, count);
 }
 
+int rtfhe_ksk_expand_ref(const rtfhe_params* p, const int32_t* key0, const int32_t* key1, const uint32_t* ksk, uint32_t* ksk_ref) {
+    if (!valid(p) || !key0 || !key1 || !ksk || !ksk_ref) return RTFHE_ERR_INVALID;
+    Source src;
+    if (!Source::from_os(src)) return RTFHE_ERR_STATE;
+    return ksk_expand_ref(p, src, key0, key1, ksk, ksk_ref);
+}
+
 // ---- TEST ONLY: reproducible from a 64-bit seed (xoshiro256**, not a CSPRNG) ----
+int rtfhe_ksk_expand_ref_deterministic(const rtfhe_params* p, uint64_t seed, const int32_t* key0, const int32_t* key1, const uint32_t* ksk, uint32_t* ksk_ref) {
+    if (!valid(p) || !key0 || !key1 || !ksk || !ksk_ref) return RTFHE_ERR_INVALID;
+    return ksk_expand_ref(p, Source::from_seed(seed), key0, key1, ksk, ksk_ref);
+}
+
 int rtfhe_keygen_deterministic(const rtfhe_params* p, uint64_t seed, int32_t* key0, int32_t* key1, uint32_t* bk, uint32_t* ksk) {
     if (!valid(p) || !key0 || !key1) return RTFHE_ERR_INVALID;
     Xoshiro root(seed);

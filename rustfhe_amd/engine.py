@@ -84,6 +84,14 @@ class Engine:
         assert ksk.size == self.p.ksk_words, "ksk must be u32[N][t][base-1][n+1]"
         self._ck(self.L.rtfhe_load_ksk(self.h, _ptr(ksk)))
 
+    def load_ksk_ref(self, ksk_ref):
+        """The reference's own shape, KeySwitchingKey(Vec<[[TLWERep; 4]; 8]>) flattened to u32[N][t][base][n+1]
+        (hom_nand/src/tlwe.rs:243-245); the never-read entry t = base of every level is dropped by the library."""
+        ksk_ref = _np(ksk_ref, np.uint32).reshape(-1)
+        base = 1 << self.p.ks_basebit
+        assert ksk_ref.size == self.p.ksk_words // (base - 1) * base, "ksk_ref must be u32[N][t][base][n+1]"
+        self._ck(self.L.rtfhe_load_ksk_ref(self.h, _ptr(ksk_ref)))
+
     def set_backend(self, backend):
         self._ck(self.L.rtfhe_set_backend(self.h, backend))
 
@@ -304,6 +312,32 @@ def phases(params, key0, cts):
 
 
 # ---- wire format (flat files; include/rtfhe.h) ----------------------------------------------------
+
+def shard_range(count, d, n_dev):
+    """[begin, end) of a count-gate host batch taken by entry d of an n_dev-device context (rtfhe_shard_range)."""
+    L = _ffi.load()
+    b, e = C.c_size_t(), C.c_size_t()
+    rc = L.rtfhe_shard_range(count, d, n_dev, C.byref(b), C.byref(e))
+    if rc != 0:
+        raise RtfheError(rc, (L.rtfhe_last_error(None) or b"").decode())
+    return b.value, e.value
+
+
+def ksk_expand_ref(params, key0, key1, ksk, seed=None):
+    """The reference's KeySwitchingKey shape u32[N][t][base][n+1] (hom_nand/src/tlwe.rs:243-245) from the compact key:
+    entries t = 1 .. base-1 copied, entry t = base encrypted afresh (seed: TEST ONLY, deterministic)."""
+    L = _ffi.load()
+    key0, key1, ksk = _np(key0, np.int32), _np(key1, np.int32), _np(ksk, np.uint32).reshape(-1)
+    base = 1 << params.ks_basebit
+    out = np.empty(params.ksk_words // (base - 1) * base, np.uint32)
+    if seed is None:
+        rc = L.rtfhe_ksk_expand_ref(C.byref(params), _ptr(key0), _ptr(key1), _ptr(ksk), _ptr(out))
+    else:
+        rc = L.rtfhe_ksk_expand_ref_deterministic(C.byref(params), seed, _ptr(key0), _ptr(key1), _ptr(ksk), _ptr(out))
+    if rc != 0:
+        raise RuntimeError("rtfhe_ksk_expand_ref failed (%d)" % rc)
+    return out.reshape(params.N, params.ks_t, base, params.n + 1)
+
 
 def save_keys(path, params, key0=None, key1=None, bk=None, ksk=None):
     L = _ffi.load()

@@ -136,11 +136,16 @@ class TFHE : public Logip<TLWERep<TLWE_N>> {
         std::vector<uint32_t> ksk((size_t)TRLWE_N * p_.ks_t * ((1 << p_.ks_basebit) - 1) * (TLWE_N + 1));
         check(nullptr, key_seed ? rtfhe_keygen_with_keys_deterministic(&p_, *key_seed, k0.data(), k1.data(), bk.data(), ksk.data())
                                 : rtfhe_keygen_with_keys(&p_, k0.data(), k1.data(), bk.data(), ksk.data()));
+        // the key-switching key goes in through the reference's own container shape, [[TLWERep; IKS_T = 4]; IKS_L = 8] per coefficient
+        // (tlwe.rs:243-245), entry t = 4 included as KeySwitchingKey::new fills it (tlwe.rs:252-274)
+        std::vector<uint32_t> ksk_ref((size_t)TRLWE_N * p_.ks_t * (1 << p_.ks_basebit) * (TLWE_N + 1));
+        check(nullptr, key_seed ? rtfhe_ksk_expand_ref_deterministic(&p_, *key_seed ^ 0x4b534b, k0.data(), k1.data(), ksk.data(), ksk_ref.data())
+                                : rtfhe_ksk_expand_ref(&p_, k0.data(), k1.data(), ksk.data(), ksk_ref.data()));
         rtfhe_ctx* c = nullptr;
         check(nullptr, rtfhe_ctx_create(&p_, device, &c));
         ctx_.reset(c, rtfhe_ctx_destroy);
         check(c, rtfhe_load_bk_torus(c, bk.data()));
-        check(c, rtfhe_load_ksk(c, ksk.data()));
+        check(c, rtfhe_load_ksk_ref(c, ksk_ref.data()));
     }
 
   public:

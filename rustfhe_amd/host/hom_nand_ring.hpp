@@ -140,7 +140,7 @@ class TRGSWRepF {
 };
 
 // BootstrappingKey<PRE_N, N>(Vec<TRGSW>) (tfhe.rs:116-135) and KeySwitchingKey<N, M> (tlwe.rs:243-293): flat containers in the
-// ABI's layouts, generated for caller-supplied secret keys; `raw()` feeds rtfhe_load_bk_torus / rtfhe_load_ksk.
+// ABI's layouts, generated for caller-supplied secret keys; `raw()` feeds rtfhe_load_bk_torus, `raw_ref()` rtfhe_load_ksk_ref.
 template <int PRE_N, int N>
 struct BootstrappingKey {
     std::vector<uint32_t> flat;       // [PRE_N][2][2l][N]
@@ -161,22 +161,27 @@ struct BootstrappingKey {
 
 template <int N, int M>
 struct KeySwitchingKey {
-    std::vector<uint32_t> flat;       // [N][IKS_L][IKS_T - 1][M + 1]
+    // the reference's container as it stands: Vec<[[TLWERep<M>; IKS_T]; IKS_L]> (tlwe.rs:243-245), IKS_T = 2^IKS_BASEBIT = 4 entries per
+    // level of which identity_key_switch only ever reads t = 1 .. 3; flat [N][IKS_L][IKS_T][M + 1] = what rtfhe_load_ksk_ref takes
+    std::vector<uint32_t> flat;
     KeySwitchingKey(const std::array<Binary, N>& pre_s_key, const std::array<Binary, M>& next_s_key, const uint64_t* seed = nullptr) {
         rtfhe_params p; rtfhe_default_params(&p); p.n = M; p.N = N; p.nbit = 0; for (int v = N; v > 1; v >>= 1) p.nbit++;
         std::vector<int32_t> k0(M), k1(N);
         for (int i = 0; i < M; i++) k0[i] = (int32_t)next_s_key[i];
         for (int i = 0; i < N; i++) k1[i] = (int32_t)pre_s_key[i];
-        flat.resize((size_t)N * TLWEHelper::IKS_L * (TLWEHelper::IKS_T - 1) * (M + 1));
-        if (seed ? rtfhe_keygen_with_keys_deterministic(&p, *seed, k0.data(), k1.data(), nullptr, flat.data())
-                 : rtfhe_keygen_with_keys(&p, k0.data(), k1.data(), nullptr, flat.data())) throw std::runtime_error("KeySwitchingKey::new");
+        std::vector<uint32_t> compact((size_t)N * TLWEHelper::IKS_L * (TLWEHelper::IKS_T - 1) * (M + 1));
+        flat.resize((size_t)N * TLWEHelper::IKS_L * TLWEHelper::IKS_T * (M + 1));
+        if (seed ? rtfhe_keygen_with_keys_deterministic(&p, *seed, k0.data(), k1.data(), nullptr, compact.data())
+                 : rtfhe_keygen_with_keys(&p, k0.data(), k1.data(), nullptr, compact.data())) throw std::runtime_error("KeySwitchingKey::new");
+        if (seed ? rtfhe_ksk_expand_ref_deterministic(&p, *seed ^ 0x4b534b, k0.data(), k1.data(), compact.data(), flat.data())
+                 : rtfhe_ksk_expand_ref(&p, k0.data(), k1.data(), compact.data(), flat.data())) throw std::runtime_error("KeySwitchingKey::new");
     }
-    // get(i, l, t) = KS[i][l][t-1] = TLWE(t * s_i / 2^(bit (l+1)))   (tlwe.rs:281-283)
+    // get(i, l, t) = KS[i][l][t-1] = TLWE(t * s_i / 2^(bit (l+1))), t = 1 .. IKS_T   (tlwe.rs:281-283)
     TLWERep<M> get(int i, int l, int t) const {
-        if (i < 0 || i >= N || l < 0 || l >= TLWEHelper::IKS_L || t < 1 || t >= TLWEHelper::IKS_T) throw std::out_of_range("KeySwitchingKey::get");
-        return TLWERep<M>::from_flat(flat.data() + (((size_t)i * TLWEHelper::IKS_L + l) * (TLWEHelper::IKS_T - 1) + (t - 1)) * (M + 1));
+        if (i < 0 || i >= N || l < 0 || l >= TLWEHelper::IKS_L || t < 1 || t > TLWEHelper::IKS_T) throw std::out_of_range("KeySwitchingKey::get");
+        return TLWERep<M>::from_flat(flat.data() + (((size_t)i * TLWEHelper::IKS_L + l) * TLWEHelper::IKS_T + (t - 1)) * (M + 1));
     }
-    const uint32_t* raw() const { return flat.data(); }
+    const uint32_t* raw_ref() const { return flat.data(); }       // feeds rtfhe_load_ksk_ref
 };
 
 }  // namespace hom_nand

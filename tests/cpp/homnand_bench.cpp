@@ -77,6 +77,10 @@ int main() {
             Torus32 s = 0; for (int i = 0; i < TLWE_N; i++) if (s0[i] == Binary::One) s += row.p_key()[i];
             const int32_t err = (int32_t)(row.cipher() - s - (s1[3] == Binary::One ? 0x40000000u : 0u));
             if (err > (1 << 21) || err < -(1 << 21)) { std::printf("KeySwitchingKey::get WRONG\n"); bad++; }
+            auto row4 = ksk.get(5, 1, TLWEHelper::IKS_T);                        // the reference's 4th entry: TLWE(4 * s1[5] / 16)
+            Torus32 s4 = 0; for (int i = 0; i < TLWE_N; i++) if (s0[i] == Binary::One) s4 += row4.p_key()[i];
+            const int32_t err4 = (int32_t)(row4.cipher() - s4 - (s1[5] == Binary::One ? 0x40000000u : 0u));
+            if (err4 > (1 << 21) || err4 < -(1 << 21)) { std::printf("KeySwitchingKey::get(t = IKS_T) WRONG\n"); bad++; }
         }
         std::printf(bad ? "FAILED %d\n" : "all truth tables ok\n", bad);
         return bad ? 1 : 0;

@@ -94,6 +94,7 @@ def lib():
         "orc_blind_rotate": (None, [PP, vp, f64p, u32p, u32p, i32, u32p]),
         "orc_sample_extract": (None, [i32, u32p, i32, u32p]),
         "orc_key_switch": (None, [PP, u32p, u32p, u32p]),
+        "orc_key_switch_ref": (None, [PP, u32p, u32p, u32p]),
         "orc_gate_linear": (None, [PP, C.c_int, u32p, u32p, u32p]),
         "orc_bootstrap": (None, [PP, vp, f64p, u32p, u32p, u32p, u32p]),
         "orc_gate": (None, [PP, vp, C.c_int, f64p, u32p, u32p, u32p, u32p, u32p]),
@@ -114,6 +115,7 @@ def lib():
         "orc_trgsw_encrypt": (None, [C.POINTER(Rng), vp, PP, i32p, i32, C.c_float, u32p]),
         "orc_bk_gen": (None, [C.POINTER(Rng), vp, PP, i32p, i32p, C.c_float, u32p]),
         "orc_ksk_gen": (None, [C.POINTER(Rng), PP, i32p, i32p, C.c_float, u32p]),
+        "orc_ksk_expand_ref": (None, [C.POINTER(Rng), PP, i32p, i32p, C.c_float, u32p, u32p]),
         "orc_fnv64": (C.c_uint64, [vp, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
@@ -268,6 +270,18 @@ class Keys:
                                params.n * 2 * 2 * params.l)
         self.rng = rng
 
+    def ksk_ref(self, seed=0x4b534b, alpha_ks=2.0 ** -15):
+        """The key-switching key in the reference's own container shape u32[N][t][base][n+1] (tlwe.rs:243-245): this key set's
+        rows plus the never-read entry t = base of every level, encrypted with a generator of its own."""
+        L = lib()
+        rng = Rng()
+        L.orc_rng_seed(C.byref(rng), seed)
+        base = 1 << self.p.ks_basebit
+        out = np.empty(self.p.ksk_words // (base - 1) * base, np.uint32)
+        L.orc_ksk_expand_ref(C.byref(rng), C.byref(self.p), _p(self.key1, C.c_int32), _p(self.key0, C.c_int32),
+                             C.c_float(alpha_ks), _p(self.ksk, C.c_uint32), _p(out, C.c_uint32))
+        return out
+
     def encrypt_bits(self, bits, alpha=2.0 ** -15, rng=None):
         L = lib()
         rng = rng or self.rng
@@ -311,6 +325,13 @@ def key_switch(params, ksk, tlwe1):
     out = np.empty(params.n + 1, np.uint32)
     lib().orc_key_switch(C.byref(params), _p(ksk, C.c_uint32), _p(np.ascontiguousarray(tlwe1, np.uint32), C.c_uint32),
                          _p(out, C.c_uint32))
+    return out
+
+
+def key_switch_ref(params, ksk_ref, tlwe1):
+    out = np.empty(params.n + 1, np.uint32)
+    lib().orc_key_switch_ref(C.byref(params), _p(ksk_ref, C.c_uint32), _p(np.ascontiguousarray(tlwe1, np.uint32), C.c_uint32),
+                             _p(out, C.c_uint32))
     return out
 
 

@@ -120,6 +120,17 @@ def test_host_keygen_encrypt_decrypt_roundtrip():
     # same seed -> same keys
     k0b, _, _, _ = R.keygen(p, 5, want_bk=False, want_ksk=False)
     assert np.array_equal(key0, k0b)
+    # the reference's container shape [[TLWERep; IKS_T = 4]; IKS_L = 8] (hom_nand/src/tlwe.rs:243-245): entries t = 1 .. 3 are the
+    # compact key's rows, entry t = 4 encrypts 4 s_i / 4^(l+1) like KeySwitchingKey::new (tlwe.rs:252-274)
+    for seed in (11, None):
+        k4 = R.ksk_expand_ref(p, key0, key1, ksk, seed)
+        assert k4.shape == (p.N, p.ks_t, 4, p.n + 1)
+        assert np.array_equal(k4[:, :, :3], rows)
+        for (i, l) in [(0, 0), (3, 2), (17, 7), (p.N - 1, 1)]:
+            got = int(R.phases(p, key0, k4[i, l, 3][None])[0])
+            want = 4 * int(key1[i]) * (1 << (32 - 2 * (l + 1))) % 2 ** 32
+            assert abs(((got - want + 2 ** 31) % 2 ** 32) - 2 ** 31) < 2 ** 21
+    assert np.array_equal(R.ksk_expand_ref(p, key0, key1, ksk, 11), R.ksk_expand_ref(p, key0, key1, ksk, 11))
 
 
 def test_production_keygen_draws_from_the_os_csprng():
@@ -172,6 +183,29 @@ def test_host_bk_is_a_valid_trgsw_set(orc):
                 want = (-g * key1.astype(np.int64)) % 2 ** 32
             err = ((ph.astype(np.int64) - want + 2 ** 31) % 2 ** 32) - 2 ** 31
             assert np.abs(err).max() < 2 ** 12, (i, j)
+
+
+def test_shard_ranges_partition_a_batch():
+    """The sharding arithmetic of a multi-device context (rtfhe_shard_range = what rtfhe_gate_batch / _mux_batch / _bootstrap_batch
+    give device d): contiguous, in order, covering [0, count) exactly, sizes within one of each other, empty shards when
+    count < n_dev; bad arguments are refused.  Pure host arithmetic: runs without a GPU."""
+    import rustfhe_amd as R
+    for n_dev in (1, 2, 3, 7, 8, 64):
+        for count in (0, 1, 2, n_dev - 1, n_dev, n_dev + 1, 1000, 1024, 65536, 65537, 2 ** 33 + 5):
+            if count < 0:
+                continue
+            edges = [R.shard_range(count, d, n_dev) for d in range(n_dev)]
+            assert edges[0][0] == 0 and edges[-1][1] == count
+            sizes = []
+            for d, (b, e) in enumerate(edges):
+                assert b <= e and (d == 0 or b == edges[d - 1][1])
+                sizes.append(e - b)
+            assert max(sizes) - min(sizes) <= 1 and sum(sizes) == count
+    # the 8-GPU split of BASELINE config 3
+    assert [R.shard_range(65536, d, 8) for d in range(8)] == [(8192 * d, 8192 * (d + 1)) for d in range(8)]
+    for bad in ((10, -1, 4), (10, 4, 4), (10, 0, 0), (10, 0, 65)):
+        with pytest.raises(R.RtfheError):
+            R.shard_range(*bad)
 
 
 def test_rust_sys_crate_declares_the_same_abi():

@@ -116,6 +116,41 @@ def test_key_switch_golden_and_oracle(engine, orc, params, keys, gold_gate):
     assert np.array_equal(out[1][:params.n], np.zeros(params.n, np.uint32)) and out[1][params.n] == t1[1, params.N]
 
 
+def test_reference_shaped_ksk_reproduces_the_golden_gates(orc, params, keys, gold_gate):
+    """rtfhe_load_ksk_ref takes KeySwitchingKey(Vec<[[TLWERep; IKS_T = 4]; IKS_L = 8]>) flattened as the reference holds it
+    (hom_nand/src/tlwe.rs:178-180, 243-245, get(i, l, t) = [i][l][t-1]): a 4-wide key built by the oracle -- the golden key set's
+    rows plus the never-read entries t = 4 -- must give the golden gates word for word, and the stage-level key switch must agree
+    with the oracle reading the 4-wide key."""
+    import rustfhe_amd as R
+    ksk_ref = keys.ksk_ref()
+    base = 1 << params.ks_basebit
+    assert ksk_ref.size == params.N * params.ks_t * base * (params.n + 1)
+    k4 = ksk_ref.reshape(params.N, params.ks_t, base, params.n + 1)
+    assert np.array_equal(k4[:, :, :base - 1].reshape(-1), keys.ksk)           # entries t = 1 .. 3 are the compact key's rows
+    # entry t = 4 is a real encryption of 4 s_i / 4^(l+1) (phase within the key-switch noise), not padding
+    ph = int(keys.phase(k4[5, 2, base - 1]))
+    want = ((int(keys.key1[5]) * base) << (32 - params.ks_basebit * 3)) % 2 ** 32
+    assert abs(((ph - want + 2 ** 31) % 2 ** 32) - 2 ** 31) < 2 ** 22
+    p = R.Params(n=params.n, N=params.N, l=params.l, bgbit=params.bgbit, ks_t=params.ks_t, ks_basebit=params.ks_basebit)
+    e = R.Engine(p, 0)
+    try:
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk_ref(ksk_ref)
+        ops, in0, in1 = gold_gate["ops"], gold_gate["in0"], gold_gate["in1"]
+        for g in range(len(ops)):
+            out = e.gate_batch(int(ops[g]), in0[g:g + 1], in1[g:g + 1])
+            assert np.array_equal(out[0], gold_gate["out"][g]), "gate %d (op %d)" % (g, ops[g])
+        rng = np.random.default_rng(16)
+        t1 = rng.integers(0, 2 ** 32, (5, params.N + 1), dtype=np.uint64).astype(np.uint32)
+        t1[0] = gold_gate["extract"]
+        t1[1, :params.N] = 0xFFFFFFFF
+        out = e.key_switch_batch(t1)
+        assert np.array_equal(out, np.stack([orc.key_switch_ref(params, ksk_ref, x) for x in t1]))
+        assert np.array_equal(out[0], gold_gate["out"][0])
+    finally:
+        e.close()
+
+
 def test_gates_golden(engine, gold_gate):
     ops, in0, in1 = gold_gate["ops"], gold_gate["in0"], gold_gate["in1"]
     for g in range(len(ops)):

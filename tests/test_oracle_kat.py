@@ -158,6 +158,25 @@ def test_sample_extract_and_key_switch_semantics(orc, params, keys):
     assert orc.lib().orc_torus2binary(ph0) == 1
 
 
+def test_key_switch_in_the_reference_container_shape(orc, params, keys, gold_gate):
+    """KeySwitchingKey(Vec<[[TLWERep; IKS_T]; IKS_L]>), IKS_T = 2^IKS_BASEBIT = 4 (hom_nand/src/tlwe.rs:178-180, 243-245):
+    get(i, l, t) = [i][l][t-1] for t = digit in 1 .. 3 -- the 4th entry of a level never enters a key switch."""
+    k4 = keys.ksk_ref()
+    base = 1 << params.ks_basebit
+    assert k4.size == keys.ksk.size // (base - 1) * base
+    rng = np.random.default_rng(21)
+    t1 = rng.integers(0, 2 ** 32, (4, params.N + 1), dtype=np.uint64).astype(np.uint32)
+    t1[0] = gold_gate["extract"]
+    t1[1, :params.N] = 0xFFFFFFFF
+    for x in t1:
+        assert np.array_equal(orc.key_switch_ref(params, k4, x), orc.key_switch(params, keys.ksk, x))
+    assert np.array_equal(orc.key_switch_ref(params, k4, t1[0]), gold_gate["out"][0])
+    # scribbling over every 4th entry changes nothing
+    k4b = k4.copy().reshape(params.N, params.ks_t, base, params.n + 1)
+    k4b[:, :, base - 1] = 0xDEADBEEF
+    assert np.array_equal(orc.key_switch_ref(params, k4b.reshape(-1), t1[2]), orc.key_switch(params, keys.ksk, t1[2]))
+
+
 def test_exact_int_backend_decrypts_like_mirror(orc, keys):
     # SURVEY H3: an exact-integer multiply gives different ciphertext bits but the same plaintext; small n keeps it fast
     small = orc.Params(n=6)
