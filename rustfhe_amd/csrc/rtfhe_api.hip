@@ -22,6 +22,7 @@
 #include "rtfhe_kernels_ntt.hpp"
 #include "rtfhe_kernels_ntt_halves.hpp"
 #include "rtfhe_kernels_ntt_wg.hpp"
+#include "rtfhe_kernels_ksmm.hpp"
 
 using namespace rtfhe;
 
@@ -221,6 +222,10 @@ struct rtfhe_ctx {
     bool ntt_ready = false;
     uint32_t* d_ksk = nullptr;
     int ksw = 0;
+    uint4* d_ksmat = nullptr;         // the key-switching key as signed byte limbs in i8-MFMA operand order (rtfhe_kernels_ksmm.hpp)
+    uint32_t* d_tlwe1 = nullptr;      // lvl1 samples between the two launches of the split path
+    size_t cap_tlwe1 = 0;             // in gates
+    int ks_mm_min = 1024;             // plain batches of at least this many gates take the split path (0 = never); RTFHE_KS_MM_MIN
     bool has_bk = false, has_ksk = false;
     void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr;   // device staging for host-pointer calls
     size_t cap_a = 0, cap_b = 0, cap_c = 0;
@@ -370,6 +375,33 @@ int launch_bootstrap_halves11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) 
     return 0;
 }
 
+// The split path of a plain batch (N = 1024, whole rounds): blind rotation + sample extract of every gate (k_bootstrap_pair in
+// MODE_EXTRACT), then the key switch of the whole batch as one exact i8 contraction on the matrix pipe (k_key_switch_mm) -- two
+// launches back to back on the caller's stream, the lvl1 samples in between stay in HBM (4 MB per 1024 gates).
+int launch_split_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    const size_t count = (size_t)a.count, N = (size_t)ctx->p.N;
+    if (ctx->cap_tlwe1 < count) {        // grows outside the steady state only (never inside a stream capture: netlist waves are fused)
+        if (ctx->d_tlwe1) HIPCHECK(ctx, hipFree(ctx->d_tlwe1));
+        ctx->d_tlwe1 = nullptr; ctx->cap_tlwe1 = 0;
+        const size_t cap = count < 8192 ? 8192 : count;
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tlwe1, cap * (N + 1) * 4));
+        ctx->cap_tlwe1 = cap;
+    }
+    uint32_t* final_out = a.out;
+    a.mode = MODE_EXTRACT; a.out = ctx->d_tlwe1;
+    if (int rc = launch_bootstrap_pair10(ctx, a, s)) return rc;
+    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 63) / 64;
+    // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
+    int splitk = 1;
+    while (splitk < 8 && (size_t)mgroups * colgroups * splitk < (size_t)8 * ctx->num_cus && (ctx->p.N / 4) % (8 * splitk) == 0) splitk *= 2;
+    HIPCHECK(ctx, hipMemsetAsync(final_out, 0, count * ((size_t)ctx->p.n + 1) * 4, s));
+    KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, final_out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk};
+    hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
 // `cnt` gates of a batch starting at gate `off` (plain batches advance the ciphertext pointers, netlist waves the index arrays)
 BootstrapArgs batch_segment(BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
     if (a.idx0) { a.ops += off; a.idx0 += off; a.idx1 += off; a.idx_out += off; }
@@ -397,8 +429,11 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * (1 << LOGN) : (size_t)a.n + 1;
         const size_t round = (size_t)4 * ctx->num_cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
-        if (full)
-            if (int rc = launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (full) {
+            const bool split = a.mode == MODE_GATE && !a.idx0 && ctx->d_ksmat && ctx->ks_mm_min > 0 && full >= (size_t)ctx->ks_mm_min;
+            if (int rc = split ? launch_split_pair10(ctx, batch_segment(a, 0, full, out_words), s)
+                               : launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        }
         if (rem) {
             const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
             if (rem <= (size_t)ctx->wg_max) return launch_bootstrap_wg10(ctx, tail, s);
@@ -901,6 +936,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
         if (const char* e = std::getenv("RTFHE_FORCE_WAVES")) ctx->force_waves = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_WG_MAX_GATES")) ctx->wg_max = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_STAGING")) ctx->stage_pinned = std::atoi(e) != 0;
+        if (const char* e = std::getenv("RTFHE_KS_MM_MIN")) ctx->ks_mm_min = std::atoi(e);
     }
     if (!rc) rc = prime_kernel_attributes(ctx);
     if (!rc) rc = upload_twiddles(ctx);
@@ -991,6 +1027,8 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
     if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);
     if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
+    if (ctx->d_ksmat) (void)hipFree(ctx->d_ksmat);
+    if (ctx->d_tlwe1) (void)hipFree(ctx->d_tlwe1);
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_b) (void)hipFree(ctx->d_b);
     if (ctx->d_c) (void)hipFree(ctx->d_c);
@@ -1112,9 +1150,22 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
     hipLaunchKernelGGL((k_ksk_combine<8, 2>), dim3(4096), dim3(256), 0, ctx->stream, a);
     HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the same key as signed byte limbs in i8-MFMA operand order, for the batch key switch of the split path (N = 1024)
+    size_t ksmat_bytes = 0;
+    if (ctx->logn == 10 && ctx->ks_mm_min > 0) {
+        const int colgroups = (ctx->p.n + 1 + 15) / 16;
+        ksmat_bytes = (size_t)colgroups * (ctx->p.N / 2) * 4 * 64 * sizeof(uint4);
+        if (!ctx->d_ksmat) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ksmat, ksmat_bytes));
+        KsMatArgs m{(const uint32_t*)ctx->d_a, ctx->d_ksmat, ctx->p.N, ctx->p.n, ctx->ksw, colgroups};
+        hipLaunchKernelGGL((k_ksmat_build<8, 2>), dim3(4096), dim3(256), 0, ctx->stream, m);
+        HIPCHECK(ctx, hipGetLastError());
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->has_ksk = true;
     for (rtfhe_ctx* peer : ctx->peers) {
         if (int rc = replicate(ctx, peer, ctx->d_ksk, (void**)&peer->d_ksk, (dev_rows + 1) * ksw * 4)) return rc;
+        if (ksmat_bytes)
+            if (int rc = replicate(ctx, peer, ctx->d_ksmat, (void**)&peer->d_ksmat, ksmat_bytes)) return rc;
         peer->has_ksk = true;
     }
     return 0;

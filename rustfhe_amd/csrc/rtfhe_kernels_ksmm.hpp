@@ -1,0 +1,155 @@
+// rtfhe_kernels_ksmm.hpp -- the identity key switch of a whole BATCH as one exact integer contraction on the i8 matrix pipe.
+//
+// identity_key_switch (hom_nand/src/tlwe.rs:43-73) subtracts, per coefficient i and level l, the row KS[i][l][digit - 1] of the
+// key from the result.  Inside the bootstrap kernel every gate gathers its own ~6,000 rows of 2.5 KB (9.8 MB per gate through the
+// L2, 10 GB per 1,024 gates: 0.52 ms of a 7.1 ms launch, with the FP64 units idle).  For a batch the same sum is a matrix product
+//
+//     S[g][col] = sum_k  H[g][k] * KS[k][col] ,   k = (i, l, d),   H[g][k] = [ digit_l(a'_i of gate g) == d ]   (one-hot)
+//
+// in which every key row is reused by all the gates of a tile instead of being fetched per gate.  It is evaluated EXACTLY:
+// each 32-bit key word is split into four signed byte limbs (w = sum_j s_j 256^j mod 2^32, s_j in [-128, 127]), the one-hot
+// operand is 0 / 1 in i8, v_mfma_i32_16x16x64_i8 accumulates in i32 (|sum| <= N t 128 = 2^20 for N = 1024: no overflow), and the
+// limb sums are recombined with shifts mod 2^32 -- the same torus words as the reference's row-by-row wrapping subtraction
+// (u32 addition is associative and commutative).  The matrix pipe is otherwise unused on this path; nothing about the blind
+// rotation changes.  This is a gather turned into a contraction to get row reuse, not a floating-point reshaping: bits are equal.
+//
+// K order (free, as long as both operands use it): K-step ks = 2 kk + h (kk < N/4, h < 2); lane group q = lane / 16 owns coefficient
+// i = q N/4 + kk; the 16 operand bytes of a lane are t = 4 j + d: level l = 4 h + j, digit value d (d = 0: a zero key row).
+// Key matrix in HBM: [colgroup = col / 16][ks][limb][lane][16 B] -- one 1 KiB dwordx4 load per MFMA operand, contiguous 4 KiB per
+// K-step of a wave.  A wave owns MT = 4 tiles of 16 gates x one column group (16 columns x 4 limbs) x one K-slice: 16 MFMAs per K-step,
+// 64 accumulator registers, key operands of 4 K-steps in flight; K-slices add their parts to the (zeroed) output with wrapping u32
+// atomics (order-free).  The grid is laid out so that all gate groups and slices of a column group share one XCD's L2
+// (blockIdx % 8 == cg % 8 when the column-group count is a multiple of 8: 40 for n = 635).
+#pragma once
+
+#include "rtfhe_kernels.hpp"
+
+namespace rtfhe {
+
+struct KsMmArgs {
+    const uint32_t* tlwe1;   // [count][N+1]: extracted lvl1 samples a'[0..N), b'
+    const uint4* kmat;       // [colgroups][N/2 K-steps][4 limbs][64 lanes] x 16 B
+    uint32_t* out;           // [count][n+1], ZERO on entry: every K-slice adds its part with a wrapping atomic (order-free in u32)
+    int32_t count, n, N, colgroups;
+    int32_t splitk;          // K-slices per (gate group, column group): N/4 must be divisible by 4 * splitk
+};
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// grid: x = (mg * splitk + slice) * colgroups + cg; one wave per block
+template <int KS_T, int KS_BB>
+__global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
+    static_assert(KS_T == 8 && KS_BB == 2, "operand packing: 4 levels x 4 digit values per 16-byte operand chunk");
+    constexpr int MT = 4, PF = 4;       // gate tiles per wave; K-steps of key operands in flight
+    constexpr uint32_t ROUND = 1u << (32 - KS_T * KS_BB - 1);
+    const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
+    const int cg = blockIdx.x % a.colgroups, rest = blockIdx.x / a.colgroups;
+    const int slice = rest % a.splitk, mg = rest / a.splitk;
+    const int quarter = a.N / 4, ksteps = a.N / 2;
+    const int kk_begin = quarter / a.splitk * slice, kk_end = kk_begin + quarter / a.splitk;     // coefficients (per lane group) of this slice
+    const int ks_end = 2 * kk_end;
+    const size_t w1 = (size_t)a.N + 1;
+    // the gates whose one-hot rows this lane builds (row r16 of each of the MT tiles); tiles past the batch shadow the last gate
+    const uint32_t* src[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int g = min((mg * MT + mt) * 16 + r16, a.count - 1);
+        src[mt] = a.tlwe1 + (size_t)g * w1 + (size_t)q * quarter;
+    }
+    v4i_t acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[mt][j] = (v4i_t){0, 0, 0, 0};
+    const uint4* kp = a.kmat + (size_t)cg * ksteps * 4 * 64 + lane;
+    uint4 ring[PF][4];
+#pragma unroll
+    for (int t = 0; t < PF; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) ring[t][j] = kp[((size_t)(2 * kk_begin + t) * 4 + j) * 64];
+    uint4 aw[MT];
+#pragma unroll 1
+    for (int kk4 = kk_begin; kk4 < kk_end; kk4 += 4) {       // 4 coefficients per lane group = 8 K-steps per trip
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+            aw[mt] = make_uint4(src[mt][kk4], src[mt][kk4 + 1], src[mt][kk4 + 2], src[mt][kk4 + 3]);   // rows of N+1 words: 4-byte aligned only
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int t = 2 * e + h, ks = 2 * kk4 + t;
+                uint4 b[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = ring[t % PF][j];
+                if (ks + PF < ks_end) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) ring[t % PF][j] = kp[((size_t)(ks + PF) * 4 + j) * 64];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const uint32_t word = (e == 0 ? aw[mt].x : e == 1 ? aw[mt].y : e == 2 ? aw[mt].z : aw[mt].w) + ROUND;
+                    const uint32_t byte8 = (word >> (24 - 8 * h)) & 0xffu;         // levels 4h .. 4h+3, most significant first
+                    v4i_t av;
+                    av.x = (int)(1u << (((byte8 >> 6) & 3u) * 8u));
+                    av.y = (int)(1u << (((byte8 >> 4) & 3u) * 8u));
+                    av.z = (int)(1u << (((byte8 >> 2) & 3u) * 8u));
+                    av.w = (int)(1u << ((byte8 & 3u) * 8u));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const v4i_t bv = {(int)b[j].x, (int)b[j].y, (int)b[j].z, (int)b[j].w};
+                        acc[mt][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc[mt][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D layout of a 16x16 i32 tile: lane holds column lane % 16, rows 4 (lane / 16) + r in register r
+    const int col = cg * 16 + r16;
+    if (col > a.n) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int g = (mg * MT + mt) * 16 + 4 * q + r;
+            if (g >= a.count) continue;
+            const uint32_t s = (uint32_t)acc[mt][0][r] + ((uint32_t)acc[mt][1][r] << 8) + ((uint32_t)acc[mt][2][r] << 16) + ((uint32_t)acc[mt][3][r] << 24);
+            const uint32_t bprime = (col == a.n && slice == 0) ? a.tlwe1[(size_t)g * w1 + a.N] : 0u;
+            atomicAdd(a.out + (size_t)g * ((size_t)a.n + 1) + col, bprime - s);
+        }
+    }
+}
+
+// key matrix from the reference-order rows: raw[(i * t + l) * (base - 1) + d - 1][ksw]  ->  signed byte limbs in operand order
+struct KsMatArgs {
+    const uint32_t* raw;     // [N * t * (base-1) (+1)][ksw]
+    uint4* kmat;
+    int32_t N, n, ksw, colgroups;
+};
+template <int KS_T, int KS_BB>
+__global__ __launch_bounds__(256) void k_ksmat_build(const KsMatArgs a) {
+    const int ksteps = a.N / 2, quarter = a.N / 4;
+    const size_t total = (size_t)a.colgroups * ksteps * 4 * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63), limb = (int)((idx >> 6) & 3);
+        const size_t rest = idx >> 8;
+        const int ks = (int)(rest % ksteps), cg = (int)(rest / ksteps);
+        const int col = cg * 16 + (lane & 15), q = lane >> 4, kk = ks >> 1, h = ks & 1, i = q * quarter + kk;
+        uint32_t out[4] = {0, 0, 0, 0};
+        if (col <= a.n) {
+            for (int t = 0; t < 16; t++) {
+                const int l = 4 * h + (t >> 2), d = t & 3;
+                if (d == 0) continue;
+                uint32_t w = a.raw[((size_t)(i * KS_T + l) * ((1 << KS_BB) - 1) + (d - 1)) * a.ksw + col];
+                int32_t s = 0;
+                for (int j = 0; j <= limb; j++) {          // balanced base-256 digits, least significant first; the last carry drops mod 2^32
+                    s = (int32_t)(int8_t)(w & 0xffu);
+                    w = (w - (uint32_t)s) >> 8;
+                }
+                out[t >> 2] |= ((uint32_t)s & 0xffu) << (8 * (t & 3));
+            }
+        }
+        a.kmat[idx] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+}  // namespace rtfhe

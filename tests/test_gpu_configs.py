@@ -376,3 +376,41 @@ def test_two_contexts_on_two_host_threads_and_context_churn(params, keys, gold_g
     for e in engines:
         e.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n", [635, 60])
+def test_batch_key_switch_on_the_matrix_pipe_equals_the_fused_kernel(orc, monkeypatch, n):
+    """Plain batches of >= 1024 gates take the split path: blind rotate + sample extract (k_bootstrap_pair, MODE_EXTRACT), then the
+    key switch of the whole batch as one exact i8 contraction (k_key_switch_mm: one-hot digits x signed byte limbs of the key,
+    i32 accumulation, limbs recombined mod 2^32).  Same torus words as the fused kernel (RTFHE_KS_MM_MIN=0) for whole rounds, for
+    rounds + a remainder and with the key-switch rows driven to their extremes, and bit-exact against the oracle."""
+    import rustfhe_amd as R
+    P = orc.Params(n=n)
+    K = orc.Keys(P, 4242 + n)
+    # extreme key rows: all-ones / 0x80.. / 0x7f.. words exercise the signed-limb carries
+    ksk = K.ksk.copy().reshape(P.N, P.ks_t, 3, n + 1)
+    ksk[0, 0, 0, :] = 0xFFFFFFFF; ksk[1, 1, 1, :] = 0x80808080; ksk[2, 2, 2, :] = 0x7F7F7F7F; ksk[3, 7, 0, :] = 0x80000000
+    ksk[4, 0, 1, :] = 0xFFFFFF80; ksk[5, 3, 2, :] = 0x00000080
+    ksk = ksk.reshape(-1)
+    p = R.Params(n=n)
+    monkeypatch.setenv("RTFHE_KS_MM_MIN", "0")
+    fused = R.Engine(p, 0)
+    monkeypatch.delenv("RTFHE_KS_MM_MIN")
+    split = R.Engine(p, 0)
+    try:
+        for e in (fused, split):
+            e.load_bk_torus(K.bk_t)
+            e.load_ksk(ksk)
+        rng = np.random.default_rng(n)
+        G = 2048 + 300
+        c0 = rng.integers(0, 2 ** 32, (G, n + 1), dtype=np.uint64).astype(np.uint32)      # arbitrary TLWE words: every digit pattern
+        c1 = rng.integers(0, 2 ** 32, (G, n + 1), dtype=np.uint64).astype(np.uint32)
+        for k in (1024, 2048, G):
+            a, b = fused.gate_batch(R.NAND, c0[:k], c1[:k]), split.gate_batch(R.NAND, c0[:k], c1[:k])
+            assert np.array_equal(a, b), k
+        pl = orc.Plan(P.N)
+        pick = rng.choice(1024, 6, replace=False)
+        exp = np.stack([orc.gate(P, pl, orc.NAND, K.bk_f, None, ksk, c0[g], c1[g]) for g in pick])
+        assert np.array_equal(b[pick], exp)
+    finally:
+        fused.close(); split.close()
