@@ -119,6 +119,9 @@ def spawn_ranks(nranks, child_cmd, timeout=None, env_extra=None):
     procs = []
     for r in range(nranks):
         env = dict(os.environ)
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's (and
+        # torch's) cross-process device-memory sharing fails with "hipIpcGetMemHandle: invalid argument".  The image exports it
+        # already; it is passed on explicitly so that a launcher with a scrubbed environment still gets working xGMI P2P.
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.update(env_extra or {})
@@ -177,27 +180,50 @@ def launch(args):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only): the oracle / the reference's own FFT on the host cores.  Checker, never product.
 # ------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """(physical cores, hardware threads) this process may run on: os.sched_getaffinity gives hardware threads (SMT siblings
+    included); physical cores = distinct (physical id, core id) pairs of those threads in /proc/cpuinfo."""
+    threads = sorted(os.sched_getaffinity(0))
+    cores = set()
+    try:
+        cur = {}
+        with open("/proc/cpuinfo") as f:
+            for ln in f.read().split("\n") + [""]:
+                if ":" in ln:
+                    k, v = ln.split(":", 1)
+                    cur[k.strip()] = v.strip()
+                elif cur:
+                    if int(cur.get("processor", -1)) in threads:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+    except OSError:
+        pass
+    return (len(cores) or len(threads)), len(threads)
+
+
 def cpu_baseline(R, params, key_bk_t, ksk, in0, in1, gpu_out, per_thread):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     import numpy as np
     import orc
-    threads = max(1, len(os.sched_getaffinity(0)))
+    cores, threads = host_cores()
     sample = min(len(in0), threads * per_thread)
+    single = min(len(in0), 16)
     p = orc.Params(n=params.n, N=params.N, l=params.l, bgbit=params.bgbit, ks_t=params.ks_t, ks_basebit=params.ks_basebit)
     pl = orc.Plan(p.N)
     bk_f = np.empty(key_bk_t.size, np.float64)
     orc.lib().orc_trgsw_to_fft(pl.h, key_bk_t.ctypes.data_as(C.POINTER(C.c_uint32)),
                                bk_f.ctypes.data_as(C.POINTER(C.c_double)), key_bk_t.size // p.N)
     timing = "timed from the moment every thread holds its FFT plan to the last thread's last gate (thread and plan creation outside)"
+    # the single-thread figure first, on an otherwise idle host (after the all-thread run the package is still clocked down)
+    one, secs1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:single], in1[:single], 1)
     out, secs = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:sample], in1[:sample], threads)
-    one, secs1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:4], in1[:4], 1)
     port = {
-        "value": round(sample / secs, 2), "unit": "gates/s", "cores": threads, "kind": "port",
-        "sample": "%d NAND gates of the same batch (%d per thread, one independent gate stream per thread; %d hardware threads = "
-                  "os.sched_getaffinity, SMT siblings included), oracle/tfhe_oracle.c FP64 mirror of the reference spqlios FFT, "
-                  "gcc -O3 -march=native -ffp-contract=off; %s" % (sample, per_thread, threads, timing),
-        "seconds": round(secs, 2), "single_thread_ms_per_gate": round(1e3 * secs1 / 4, 2),
+        "value": round(sample / secs, 2), "unit": "gates/s", "cores": cores, "hw_threads": threads, "threads_used": threads, "kind": "port",
+        "sample": "%d NAND gates of the same batch (%d per thread, one independent gate stream per thread on each of the %d hardware "
+                  "threads of %d physical cores), oracle/tfhe_oracle.c FP64 mirror of the reference spqlios FFT, "
+                  "gcc -O3 -march=native -ffp-contract=off; %s" % (sample, per_thread, threads, cores, timing),
+        "seconds": round(secs, 2), "single_thread_ms_per_gate": round(1e3 * secs1 / single, 2), "single_thread_sample_gates": single,
         "matches_gpu_bit_exact": bool(np.array_equal(out, gpu_out[:sample])),
     }
     if not orc.have_ref():
@@ -205,17 +231,122 @@ def cpu_baseline(R, params, key_bk_t, ksk, in0, in1, gpu_out, per_thread):
     # the reference's OWN compiled native FFT (oracle/_ref: utils/src/spqlios/*.cpp + AVX .s built with its build.rs flags)
     # under the restated Rust glue (the Rust half cannot be built here: no toolchain); one handle per thread
     orc.use_reference_fft_in_mt()
+    one_r, secs_r1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:single], in1[:single], 1, backend=orc.BACKEND_HOOK)
     out_r, secs_r = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:sample], in1[:sample], threads, backend=orc.BACKEND_HOOK)
-    one_r, secs_r1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:4], in1[:4], 1, backend=orc.BACKEND_HOOK)
     return {
-        "value": round(sample / secs_r, 2), "unit": "gates/s", "cores": threads, "kind": "reference",
-        "sample": "%d NAND gates of the same batch (%d per thread, one gate stream + one Spqlios handle per thread; %d hardware threads "
-                  "= os.sched_getaffinity, SMT siblings included): the reference's own compiled spqlios AVX FFT (oracle/_ref, flags of "
-                  "utils/build.rs) under the C restatement of its Rust glue; %s" % (sample, per_thread, threads, timing),
-        "seconds": round(secs_r, 2), "single_thread_ms_per_gate": round(1e3 * secs_r1 / 4, 2),
+        "value": round(sample / secs_r, 2), "unit": "gates/s", "cores": cores, "hw_threads": threads, "threads_used": threads, "kind": "reference",
+        "sample": "%d NAND gates of the same batch (%d per thread, one gate stream + one Spqlios handle per thread on each of the %d "
+                  "hardware threads of %d physical cores): the reference's own compiled spqlios AVX FFT (oracle/_ref, flags of "
+                  "utils/build.rs) under the C restatement of its Rust glue; %s" % (sample, per_thread, threads, cores, timing),
+        "seconds": round(secs_r, 2), "single_thread_ms_per_gate": round(1e3 * secs_r1 / single, 2), "single_thread_sample_gates": single,
         "matches_gpu_bit_exact": bool(np.array_equal(out_r, gpu_out[:sample])),
         "port": port,
     }
+
+
+def fp64_frac(dp_per_cmux, n, gates, seconds):
+    """fraction of the FP64 vector-issue ceiling a launch of `gates` gates taking `seconds` reaches"""
+    return round(dp_per_cmux * n * 64 * gates / seconds / FP64_VALU_PEAK, 4)
+
+
+def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np):
+    """The other BASELINE configs and the NTT backend, measured in the same run on the same GPU (rank 0, N = 1): each entry times
+    its launches with HIP events on the launch stream, names the kernel that dominates it and that kernel's fraction of the FP64
+    vector-issue ceiling.  Correctness of every entry is checked by decryption here and bit for bit by tests/ (-m gpu)."""
+    from rustfhe_amd.circuit import CircuitRunner, prefix_adder, ripple_carry_adder
+    from rustfhe_amd.shard import ShardedGates, engine_compute
+    sec = {}
+    ops = dp_wave_instr_per_cmux(params.N, params.l)["total"]
+    rng = np.random.default_rng(77)
+
+    def timed(e, fn, reps):
+        fn(); e.sync(stream)
+        e.timer_begin(stream)
+        for _ in range(reps):
+            fn()
+        ms, ks_ms, n = e.timer_end_detail(stream)
+        return ms / reps, ks_ms / reps
+
+    # -- BASELINE configs[0]: a single HomNAND gate (latency shape: one gate per 8-wave workgroup)
+    b = rng.integers(0, 2, (2, 8)).astype(np.uint8)
+    c0 = torch.from_numpy(R.encrypt_bits(params, key0, b[0], 11).view(np.int32)).to(gpu)
+    c1 = torch.from_numpy(R.encrypt_bits(params, key0, b[1], 12).view(np.int32)).to(gpu)
+    o = torch.empty_like(c0)
+    ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, c0, c1, o, 1, stream), 5)
+    sec["config1_single_gate"] = {"ms_per_gate": round(ms, 4), "kernel": "k_bootstrap_wg", "roofline_frac_fp64": fp64_frac(ops, params.n, 1, ms * 1e-3),
+                                  "note": "one gate on one CU: the fraction is of the WHOLE chip's ceiling (1/256 of it is reachable)"}
+    # -- BASELINE configs[2] on one GPU: 8192 gates held on the device, scatter -> bootstrap -> gather inside the timed step
+    G3 = 8192
+    bb = rng.integers(0, 2, (2, G3)).astype(np.uint8)
+    f0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 21).view(np.int32)).to(gpu)
+    f1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 22).view(np.int32)).to(gpu)
+    sg = ShardedGates(engine_compute(eng, gpu), params.n + 1, gpu)
+    sg.run(R.NAND, f0, f1, G3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.timer_begin(stream)
+    res = sg.run(R.NAND, f0, f1, G3, sync=torch.cuda.synchronize)
+    ms3, ks3, n3 = eng.timer_end_detail(stream)
+    torch.cuda.synchronize()
+    wall3 = time.perf_counter() - t0
+    ok3 = bool(np.array_equal(R.decrypt_bits(params, key0, res.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+    sec["config3_8192_gates_one_gpu"] = {"gates_per_s": round(G3 / wall3, 1), "ms_per_step": round(wall3 * 1e3, 3),
+                                         "phase_ms": {k: round(1e3 * v, 3) for k, v in sg.last_timing.items()},
+                                         "kernel": "k_bootstrap_pair", "kernel_ms": round(ms3 - ks3, 3), "key_switch_kernel_ms": round(ks3, 3),
+                                         "roofline_frac_fp64": fp64_frac(ops, params.n, G3, (ms3 - ks3) * 1e-3), "ok": ok3}
+    del f0, f1, res
+    # -- BASELINE configs[3]: the 8-bit adder as a NAND netlist through the front-end, one replica, whole netlist = one HIP graph
+    adders = {}
+    for name, net in (("ripple_carry_nand_only", ripple_carry_adder(8, True)), ("ripple_carry_xor_and_or", ripple_carry_adder(8, False)),
+                      ("parallel_prefix_nand_only", prefix_adder(8, True)), ("parallel_prefix_xor_and_or", prefix_adder(8, False))):
+        A, B = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+        bits = np.array([(A >> i) & 1 for i in range(8)] + [(B >> i) & 1 for i in range(8)], np.uint8)
+        run = CircuitRunner(eng, net, 1)
+        run.set_inputs(R.encrypt_bits(params, key0, bits, 31).reshape(1, 16, params.n + 1))
+        run.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dec = R.decrypt_bits(params, key0, run.outputs().reshape(-1, params.n + 1))
+        d = net.describe()
+        adders[name] = {"ms_per_addition": round(dt * 1e3, 3), "gates": d["gates"], "levels": d["depth"], "kernel": "k_bootstrap_wg",
+                        "roofline_frac_fp64": fp64_frac(ops, params.n, d["gates"], dt), "ok": int((dec * (1 << np.arange(9))).sum()) == A + B}
+        run.close()
+    sec["config4_adder_8bit_one_replica"] = adders
+    # -- the NTT backend north_star names, 1024 gates (exact-integer arithmetic; decrypt-level parity with the reference)
+    G = 1024
+    bb = rng.integers(0, 2, (2, G)).astype(np.uint8)
+    d0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 41).view(np.int32)).to(gpu)
+    d1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 42).view(np.int32)).to(gpu)
+    do = torch.empty_like(d0)
+    eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+    ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, d0, d1, do, G, stream), 3)
+    okn = bool(np.array_equal(R.decrypt_bits(params, key0, do.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+    eng.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+    nops = ntt_dp_wave_instr_per_cmux(params.N, params.l)["total"]
+    sec["ntt_exact_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_ntt_pair",
+                                   "roofline_frac_fp64": fp64_frac(nops, params.n, G, ms * 1e-3), "ok": okn}
+    # -- BASELINE configs[4]: N = 2048, 1024 gates (its own key set and context)
+    p5 = R.Params(N=2048)
+    k0, k1, bk5, ksk5 = R.keygen(p5, 20482048)
+    e5 = R.Engine(p5, gpu.index)
+    try:
+        e5.load_bk_torus(bk5)
+        e5.load_ksk(ksk5)
+        del bk5, ksk5
+        x0 = torch.from_numpy(R.encrypt_bits(p5, k0, bb[0], 51).view(np.int32)).to(gpu)
+        x1 = torch.from_numpy(R.encrypt_bits(p5, k0, bb[1], 52).view(np.int32)).to(gpu)
+        xo = torch.empty_like(x0)
+        ms, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xo, G, stream), 3)
+        ok5 = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+        ops5 = dp_wave_instr_per_cmux(2048, p5.l)["total"]
+        sec["config5_n2048_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_halves",
+                                           "dp_wave_instr_per_cmux": ops5, "roofline_frac_fp64": fp64_frac(ops5, p5.n, G, ms * 1e-3), "ok": ok5}
+    finally:
+        e5.close()
+    return sec
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -261,6 +392,13 @@ def run_rank(args):
             dist.init_process_group(backend)
         assert dist.get_world_size() == world
     n_gpus = dist.get_world_size() if dist is not None else 1     # the ranks the communicator really has
+    if world > 1 or os.environ.get("RTFHE_BENCH_FORCE_PG"):
+        # one line per rank on stderr: enough to read a first multi-GPU run from its log (which card, which peers it can reach over
+        # xGMI / P2P, what the communicator looks like)
+        peers = [d for d in range(ndev) if d != dev and torch.cuda.can_device_access_peer(dev, d)]
+        sys.stderr.write("bench.py rank %d/%d: device %d of %d (%s), backend %s, communicator world size %d, P2P-reachable peers %s, "
+                         "HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (rank, world, dev, ndev, torch.cuda.get_device_name(dev), backend, n_gpus, peers,
+                                                              os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
 
     # ---- keys: generated ONCE (rank 0) and broadcast to the other ranks (RCCL), then loaded into each rank's engine ----
     params = R.Params()
@@ -315,7 +453,7 @@ def run_rank(args):
             res = sg.run(R.NAND, full0, full1, total, sync=torch.cuda.synchronize)
             for k in acc:
                 acc[k] += sg.last_timing[k]
-        kern_ms, launches = eng.timer_end(stream)
+        kern_ms, ks_ms, launches = eng.timer_end_detail(stream)
         barrier()
         elapsed = time.perf_counter() - t0
         phase = {k.replace("_s", "_ms_per_step"): round(1e3 * v / args.steps, 3) for k, v in acc.items()}
@@ -338,7 +476,7 @@ def run_rank(args):
         eng.timer_begin(stream)
         for _ in range(args.steps):
             eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
-        kern_ms, launches = eng.timer_end(stream)
+        kern_ms, ks_ms, launches = eng.timer_end_detail(stream)
         barrier()
         elapsed = time.perf_counter() - t0
         out = d_out.cpu().numpy().view(np.uint32)
@@ -351,7 +489,9 @@ def run_rank(args):
 
     if rank == 0:
         value = n_gpus * G * args.steps / elapsed
-        launch_s = kern_ms * 1e-3 / args.steps          # device time of one batch on this rank (HIP events on the launch stream)
+        step_s = kern_ms * 1e-3 / args.steps            # device time of one batch on this rank (HIP events on the launch stream)
+        ks_s = ks_ms * 1e-3 / args.steps                # of it: the batch key switch of the split path (its own launch; 0 when fused)
+        launch_s = step_s - ks_s                        # the dominant kernel: blind rotation (+ fused key switch when not split)
         mirror = args.backend == "fft64-mirror"
         kernel = "k_bootstrap_pair" if mirror else "k_bootstrap_ntt_pair"
         ops = dp_wave_instr_per_cmux(params.N, params.l)
@@ -382,11 +522,23 @@ def run_rank(args):
                 "frac": round(achieved / FP64_VALU_PEAK, 4), "traffic": None, "kernel": kernel, "avg_launch_ms": round(1e3 * launch_s, 3),
                 "peak_is": "%d CU x %d SIMD x %d DP lanes/clk x %.1f GHz (MI355X_MICROARCH.md max clock)" % (CUS, SIMDS_PER_CU, DP_LANES_PER_CLK, CLOCK_HZ / 1e9),
                 "dp_wave_instr_per_gate": dp_gate, "dp_wave_instr_per_cmux": ops, "gates_per_launch": G,
-                "launches_per_batch": round(launches / args.steps, 2),
+                "launches_per_batch": round(launches / args.steps, 2), "device_ms_per_batch": round(1e3 * step_s, 3),
+                "timing": "HIP events on the launch stream over the timed steps; avg_launch_ms = (whole batch - the key-switch launches, "
+                          "which are bracketed by events of their own) / steps",
                 # SURVEY 8(d)'s streaming model, kept for the record: it is NOT a bound for a batch that shares bk_i through L2
                 "hbm_algorithmic": {"bytes_per_gate": ALG_BYTES_PER_GATE, "GBps": round(ALG_BYTES_PER_GATE * G / launch_s / 1e9, 2),
                                     "vs_hbm_peak": round(ALG_BYTES_PER_GATE * G / launch_s / HBM_PEAK, 4), "hbm_peak_GBps": HBM_PEAK / 1e9},
             }
+            if ks_s > 0:
+                # the second launch of a batch: the key switch of all G gates as one exact i8 contraction on the matrix pipe
+                # (one-hot digits x signed byte limbs; rtfhe_kernels_ksmm.hpp).  M = gates, N = 16 ceil((n+1)/16) x 4 limbs, K = N_ring 8 x 4.
+                mm_ops = 2.0 * G * (16 * ((params.n + 1 + 15) // 16) * 4) * (params.N * params.ks_t * 4)
+                line["roofline"]["key_switch_kernel"] = {
+                    "kernel": "k_key_switch_mm", "avg_launch_ms": round(1e3 * ks_s, 4), "bound": "mfma", "unit": "Pops/s (i8)",
+                    "achieved": round(mm_ops / ks_s / 1e15, 4), "peak": 5.0, "frac": round(mm_ops / ks_s / 5.0e15, 4),
+                    "peak_is": "dense i8 MFMA = 2 x the ~2.5 PF bf16 peak (MI355X_MICROARCH.md, Matrix cores)",
+                    "share_of_batch": round(ks_s / step_s, 4),
+                    "note": "includes the memset of the output; 25 % of the contraction's K are the zero rows of digit 0"}
         else:
             # same ceiling (FP64-rate vector issue; the NTT's v_fma_f64 count as one instruction each)
             nops = ntt_dp_wave_instr_per_cmux(params.N, params.l)
@@ -409,10 +561,14 @@ def run_rank(args):
             if j.get("gates_per_launch") == G and j.get("kernel") == kernel and j.get("src_hash") == kernel_src_hash():
                 line["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
                 line["roofline"]["traffic_source"] = j.get("source")
+                line["roofline"]["traffic_measured_in_this_run"] = False     # a builder-side rocprofv3 --pmc profile of the same device code
             else:
                 line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json is from other device code or another launch shape: not quoted"
         if n_gpus == 1 and not args.no_cpu_baseline and mirror and not config3:
             line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
+        if n_gpus == 1 and not args.no_secondary and mirror and not config3 and not args.gates:
+            # the other BASELINE configs + the NTT backend on the same clock (headline fields above are not touched by this)
+            line["secondary"] = secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
@@ -435,6 +591,7 @@ def main():
     ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact"], default="fft64-mirror",
                     help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs / NTT backend measured after the headline")
     ap.add_argument("--cpu-gates-per-thread", type=int, default=24)
     args = ap.parse_args()
     if args.gpus < 1:

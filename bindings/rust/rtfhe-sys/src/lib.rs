@@ -73,6 +73,7 @@ extern "C" {
     pub fn rtfhe_sync(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
     pub fn rtfhe_timer_begin(ctx: *mut rtfhe_ctx, stream: *mut c_void) -> c_int;
     pub fn rtfhe_timer_end(ctx: *mut rtfhe_ctx, stream: *mut c_void, ms: *mut f64, launches: *mut i64) -> c_int;
+    pub fn rtfhe_timer_end_detail(ctx: *mut rtfhe_ctx, stream: *mut c_void, ms: *mut f64, key_switch_ms: *mut f64, launches: *mut i64) -> c_int;
 
     pub fn rtfhe_blind_rotate_batch(ctx: *mut rtfhe_ctx, tlwe: *const u32, steps: i32, acc: *mut u32, count: usize) -> c_int;
     pub fn rtfhe_external_product_batch(ctx: *mut rtfhe_ctx, bk_index: *const i32, trlwe: *const u32, out: *mut u32, count: usize) -> c_int;

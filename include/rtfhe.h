@@ -167,6 +167,9 @@ int rtfhe_sync(rtfhe_ctx *ctx, void *stream);
  * `stream`); end returns total milliseconds and the number of kernel launches */
 int rtfhe_timer_begin(rtfhe_ctx *ctx, void *stream);
 int rtfhe_timer_end(rtfhe_ctx *ctx, void *stream, double *ms, int64_t *launches);
+/* the same, and of the total the device time spent in the batch key switches of the split path (plain batches of >= 1024 gates at
+ * N = 1024 run blind rotation + sample extract and the key switch of the whole batch as two launches; 0 when all were fused) */
+int rtfhe_timer_end_detail(rtfhe_ctx *ctx, void *stream, double *ms, double *key_switch_ms, int64_t *launches);
 
 /* ---- stage-level entry points (parity tests; same kernels' building blocks) ---- */
 int rtfhe_blind_rotate_batch(rtfhe_ctx *ctx, const uint32_t *tlwe /* [count][n+1] */, int32_t steps,

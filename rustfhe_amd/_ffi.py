@@ -66,6 +66,7 @@ _SIGNATURES = {
     "rtfhe_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_timer_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "rtfhe_timer_end_detail": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "rtfhe_blind_rotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "rtfhe_external_product_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_key_switch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -236,6 +236,11 @@ struct rtfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t launches = 0;
+    // between rtfhe_timer_begin and _end every batch key switch of the split path is bracketed by a pair of events of its own, so
+    // that the timer can report the blind-rotation kernel's and the key-switch kernel's device time separately
+    bool timing = false;
+    std::vector<hipEvent_t> ks_events;     // pool, pairs (before memset + k_key_switch_mm, after)
+    size_t ks_events_used = 0;
     int32_t* d_fault = nullptr;            // set by a kernel that skipped a netlist gate (bad wire index / opcode)
     unsigned long long* d_dbg = nullptr;   // RTFHE_WG_STAMPS builds: 128 words of phase timings
     std::unordered_map<const void*, size_t> lds_allowed;   // kernel -> dynamic LDS bytes already granted on this device
@@ -394,10 +399,18 @@ int launch_split_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
     int splitk = 1;
     while (splitk < 8 && (size_t)mgroups * colgroups * splitk < (size_t)8 * ctx->num_cus && (ctx->p.N / 4) % (8 * splitk) == 0) splitk *= 2;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (ctx->timing) {
+        while (ctx->ks_events.size() < ctx->ks_events_used + 2) { hipEvent_t e; HIPCHECK(ctx, hipEventCreate(&e)); ctx->ks_events.push_back(e); }
+        ev_a = ctx->ks_events[ctx->ks_events_used]; ev_b = ctx->ks_events[ctx->ks_events_used + 1];
+        ctx->ks_events_used += 2;
+        HIPCHECK(ctx, hipEventRecord(ev_a, s));
+    }
     HIPCHECK(ctx, hipMemsetAsync(final_out, 0, count * ((size_t)ctx->p.n + 1) * 4, s));
     KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, final_out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk};
     hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
     HIPCHECK(ctx, hipGetLastError());
+    if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
     ctx->launches++;
     return 0;
 }
@@ -1034,6 +1047,7 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_c) (void)hipFree(ctx->d_c);
     for (void* h : ctx->h_pin) if (h) (void)hipHostFree(h);
     for (void* m : ctx->h_mux) if (m) (void)hipFree(m);
+    for (hipEvent_t e : ctx->ks_events) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1284,19 +1298,36 @@ int rtfhe_sync(rtfhe_ctx* ctx, void* stream) {
 int rtfhe_timer_begin(rtfhe_ctx* ctx, void* stream) {
     if (int rc = use(ctx)) return rc;
     ctx->launches = 0;
+    ctx->timing = true;
+    ctx->ks_events_used = 0;
     HIPCHECK(ctx, hipEventRecord(ctx->ev0, (hipStream_t)stream));
     return 0;
 }
 
-int rtfhe_timer_end(rtfhe_ctx* ctx, void* stream, double* ms, int64_t* launches) {
+// total device time between begin and end, and of it the time inside the batch key switches of the split path (memset +
+// k_key_switch_mm; 0 when every launch was the fused kernel): total - key_switch = the blind-rotation kernels (+ launch gaps)
+int rtfhe_timer_end_detail(rtfhe_ctx* ctx, void* stream, double* ms, double* key_switch_ms, int64_t* launches) {
     if (int rc = use(ctx)) return rc;
+    ctx->timing = false;
     HIPCHECK(ctx, hipEventRecord(ctx->ev1, (hipStream_t)stream));
     HIPCHECK(ctx, hipEventSynchronize(ctx->ev1));
     float f = 0.f;
     HIPCHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
     if (ms) *ms = (double)f;
+    double ks = 0.0;
+    for (size_t i = 0; i + 1 < ctx->ks_events_used; i += 2) {
+        float g = 0.f;
+        HIPCHECK(ctx, hipEventElapsedTime(&g, ctx->ks_events[i], ctx->ks_events[i + 1]));
+        ks += (double)g;
+    }
+    ctx->ks_events_used = 0;
+    if (key_switch_ms) *key_switch_ms = ks;
     if (launches) *launches = ctx->launches;
     return 0;
+}
+
+int rtfhe_timer_end(rtfhe_ctx* ctx, void* stream, double* ms, int64_t* launches) {
+    return rtfhe_timer_end_detail(ctx, stream, ms, nullptr, launches);
 }
 
 static int run_host_bootstrap_one(rtfhe_ctx* ctx, int op, int mode, int steps, const uint32_t* in0, const uint32_t* in1,

@@ -85,6 +85,9 @@ __device__ __forceinline__ void inv_stage(double (&x)[R], const double* z) {
     }
 }
 
+// (plain accesses: the compiler pairs them into ds_read2_b64 / ds_write2_b64.  Unpaired -- lds_st / lds_ld of rtfhe_device.hpp, which
+// gains 1-3 % in the FFT kernels -- measured 1.3 % (N = 1024) and 2.8 % (N = 2048) SLOWER here: 16 values per lane are twice as many DS
+// instructions per exchange and the wave's 16-deep LDS queue fills; profiles/r03/lds_paired_vs_unpaired_all_kernels.log)
 template <int FROM, int TO>
 __device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xbuf, int lane) {
     auto slot = [&](int layout, int m) {
@@ -92,10 +95,10 @@ __device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xb
         return (FROM + TO == 3) ? GN::f1(pos) : GN::f2(pos);
     };
 #pragma unroll
-    for (int m = 0; m < R; m++) lds_st(&xbuf[slot(FROM, m)], x[m]);
+    for (int m = 0; m < R; m++) xbuf[slot(FROM, m)] = x[m];
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = lds_ld(&xbuf[slot(TO, m)]);
+    for (int m = 0; m < R; m++) x[m] = xbuf[slot(TO, m)];
     wave_lds_sync();
 }
 
@@ -146,14 +149,14 @@ __device__ __forceinline__ void forward(double (&x)[R], const double* __restrict
 // (forward_b_send), the second reads it and runs pass 3 (forward_b_receive).  The caller orders the two (release / acquire).
 __device__ __forceinline__ void forward_b_send(const double (&x)[R], double* __restrict__ xbuf, int lane) {
 #pragma unroll
-    for (int m = 0; m < R; m++) lds_st(&xbuf[GN::f2(GN::pos2(lane, m))], x[m]);
+    for (int m = 0; m < R; m++) xbuf[GN::f2(GN::pos2(lane, m))] = x[m];
 }
 __device__ __forceinline__ void forward_b_receive(double (&x)[R], const double* __restrict__ tw, const double* __restrict__ xbuf, int lane) {
     double z3[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) z3[e] = tw[TW_P3 + e * 64 + lane];
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = lds_ld(&xbuf[GN::f2(GN::pos3(lane, m))]);
+    for (int m = 0; m < R; m++) x[m] = xbuf[GN::f2(GN::pos3(lane, m))];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         if (m & 2) continue;

@@ -180,6 +180,12 @@ class Engine:
         self._ck(self.L.rtfhe_timer_end(self.h, C.c_void_p(stream) if stream else None, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def timer_end_detail(self, stream=None):
+        """(total ms, ms of it inside the batch key switches of the split path, kernel launches)"""
+        ms, ks, n = C.c_double(), C.c_double(), C.c_int64()
+        self._ck(self.L.rtfhe_timer_end_detail(self.h, C.c_void_p(stream) if stream else None, C.byref(ms), C.byref(ks), C.byref(n)))
+        return ms.value, ks.value, n.value
+
     # ---- stage level ------------------------------------------------------------------------
     def blind_rotate_batch(self, tlwe, steps=None):
         tlwe = _np(tlwe, np.uint32).reshape(-1, self.p.n + 1)
