@@ -333,6 +333,46 @@ int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
     return 0;
 }
 
+// The split path of a plain batch (whole rounds of the two-waves-per-gate kernels): blind rotation + sample extract of every gate
+// (the bootstrap kernel in MODE_EXTRACT, launched by `blind_rotate`), then the key switch of the whole batch as one exact i8
+// contraction on the matrix pipe (k_key_switch_mm) -- two launches back to back on the caller's stream, the lvl1 samples in between
+// stay in HBM (4 MB per 1024 gates at N = 1024).
+bool split_ok(const rtfhe_ctx* ctx, const BootstrapArgs& a, size_t full) {
+    return a.mode == MODE_GATE && !a.idx0 && ctx->d_ksmat && ctx->ks_mm_min > 0 && full >= (size_t)ctx->ks_mm_min;
+}
+template <typename F>
+int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate) {
+    const size_t count = (size_t)a.count, N = (size_t)ctx->p.N;
+    if (ctx->cap_tlwe1 < count) {        // grows outside the steady state only (never inside a stream capture: netlist waves are fused)
+        if (ctx->d_tlwe1) HIPCHECK(ctx, hipFree(ctx->d_tlwe1));
+        ctx->d_tlwe1 = nullptr; ctx->cap_tlwe1 = 0;
+        const size_t cap = count < 8192 ? 8192 : count;
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tlwe1, cap * (N + 1) * 4));
+        ctx->cap_tlwe1 = cap;
+    }
+    uint32_t* final_out = a.out;
+    a.mode = MODE_EXTRACT; a.out = ctx->d_tlwe1;
+    if (int rc = blind_rotate(ctx, a, s)) return rc;
+    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 63) / 64;
+    // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
+    int splitk = 1;
+    while (splitk < 8 && (size_t)mgroups * colgroups * splitk < (size_t)8 * ctx->num_cus && (ctx->p.N / 4) % (8 * splitk) == 0) splitk *= 2;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (ctx->timing) {
+        while (ctx->ks_events.size() < ctx->ks_events_used + 2) { hipEvent_t e; HIPCHECK(ctx, hipEventCreate(&e)); ctx->ks_events.push_back(e); }
+        ev_a = ctx->ks_events[ctx->ks_events_used]; ev_b = ctx->ks_events[ctx->ks_events_used + 1];
+        ctx->ks_events_used += 2;
+        HIPCHECK(ctx, hipEventRecord(ev_a, s));
+    }
+    HIPCHECK(ctx, hipMemsetAsync(final_out, 0, count * ((size_t)ctx->p.n + 1) * 4, s));
+    KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, final_out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk};
+    hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
+    HIPCHECK(ctx, hipGetLastError());
+    if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
+    ctx->launches++;
+    return 0;
+}
+
 template <int LOGN, int W>
 int launch_bootstrap_w(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     auto k = k_bootstrap<LOGN, 3, 6, 8, 2, KSQ, W>;
@@ -380,41 +420,6 @@ int launch_bootstrap_halves11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) 
     return 0;
 }
 
-// The split path of a plain batch (N = 1024, whole rounds): blind rotation + sample extract of every gate (k_bootstrap_pair in
-// MODE_EXTRACT), then the key switch of the whole batch as one exact i8 contraction on the matrix pipe (k_key_switch_mm) -- two
-// launches back to back on the caller's stream, the lvl1 samples in between stay in HBM (4 MB per 1024 gates).
-int launch_split_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    const size_t count = (size_t)a.count, N = (size_t)ctx->p.N;
-    if (ctx->cap_tlwe1 < count) {        // grows outside the steady state only (never inside a stream capture: netlist waves are fused)
-        if (ctx->d_tlwe1) HIPCHECK(ctx, hipFree(ctx->d_tlwe1));
-        ctx->d_tlwe1 = nullptr; ctx->cap_tlwe1 = 0;
-        const size_t cap = count < 8192 ? 8192 : count;
-        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tlwe1, cap * (N + 1) * 4));
-        ctx->cap_tlwe1 = cap;
-    }
-    uint32_t* final_out = a.out;
-    a.mode = MODE_EXTRACT; a.out = ctx->d_tlwe1;
-    if (int rc = launch_bootstrap_pair10(ctx, a, s)) return rc;
-    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 63) / 64;
-    // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
-    int splitk = 1;
-    while (splitk < 8 && (size_t)mgroups * colgroups * splitk < (size_t)8 * ctx->num_cus && (ctx->p.N / 4) % (8 * splitk) == 0) splitk *= 2;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    if (ctx->timing) {
-        while (ctx->ks_events.size() < ctx->ks_events_used + 2) { hipEvent_t e; HIPCHECK(ctx, hipEventCreate(&e)); ctx->ks_events.push_back(e); }
-        ev_a = ctx->ks_events[ctx->ks_events_used]; ev_b = ctx->ks_events[ctx->ks_events_used + 1];
-        ctx->ks_events_used += 2;
-        HIPCHECK(ctx, hipEventRecord(ev_a, s));
-    }
-    HIPCHECK(ctx, hipMemsetAsync(final_out, 0, count * ((size_t)ctx->p.n + 1) * 4, s));
-    KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, final_out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk};
-    hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
-    HIPCHECK(ctx, hipGetLastError());
-    if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
-    ctx->launches++;
-    return 0;
-}
-
 // `cnt` gates of a batch starting at gate `off` (plain batches advance the ciphertext pointers, netlist waves the index arrays)
 BootstrapArgs batch_segment(BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
     if (a.idx0) { a.ops += off; a.idx0 += off; a.idx1 += off; a.idx_out += off; }
@@ -443,9 +448,8 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         const size_t round = (size_t)4 * ctx->num_cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
         if (full) {
-            const bool split = a.mode == MODE_GATE && !a.idx0 && ctx->d_ksmat && ctx->ks_mm_min > 0 && full >= (size_t)ctx->ks_mm_min;
-            if (int rc = split ? launch_split_pair10(ctx, batch_segment(a, 0, full, out_words), s)
-                               : launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+            if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_pair10)
+                                                : launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
         }
         if (rem) {
             const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
@@ -465,7 +469,8 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
         if (full)
-            if (int rc = launch_bootstrap_halves11_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+            if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_halves11_g<4>)
+                                                : launch_bootstrap_halves11_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
         if (!rem) return 0;
         const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
         if (rem <= cus) return launch_bootstrap_halves11_g<1>(ctx, tail, s);
@@ -617,7 +622,8 @@ int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
     if (full)
-        if (int rc = launch_bootstrap_ntt_pair_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_ntt_pair_g<4>)
+                                            : launch_bootstrap_ntt_pair_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
     const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
     if (rem <= cus) return ctx->force_waves == 2 ? launch_bootstrap_ntt_pair_g<1>(ctx, tail, s) : launch_bootstrap_ntt_wg(ctx, tail, s);
@@ -647,7 +653,8 @@ int launch_bootstrap_ntt_halves(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) 
     const size_t cus = (size_t)ctx->num_cus, round = NTT_HALVES_ROUND * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
     if (full)
-        if (int rc = launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>)
+                                            : launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
     const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
     if (rem <= cus || NTT_HALVES_ROUND == 1) return launch_bootstrap_ntt_halves_g<1>(ctx, tail, s);
@@ -1164,9 +1171,9 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
     hipLaunchKernelGGL((k_ksk_combine<8, 2>), dim3(4096), dim3(256), 0, ctx->stream, a);
     HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // the same key as signed byte limbs in i8-MFMA operand order, for the batch key switch of the split path (N = 1024)
+    // the same key as signed byte limbs in i8-MFMA operand order, for the batch key switch of the split path
     size_t ksmat_bytes = 0;
-    if (ctx->logn == 10 && ctx->ks_mm_min > 0) {
+    if (ctx->ks_mm_min > 0) {
         const int colgroups = (ctx->p.n + 1 + 15) / 16;
         ksmat_bytes = (size_t)colgroups * (ctx->p.N / 2) * 4 * 64 * sizeof(uint4);
         if (!ctx->d_ksmat) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ksmat, ksmat_bytes));

@@ -317,6 +317,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
         }
     }
     __syncthreads();
+    if (a.mode == MODE_EXTRACT) {      // the key switch of the whole batch follows as its own launch (k_key_switch_mm)
+        if (live) {
+            uint32_t* o = a.out + (size_t)g * (N + 1);
+            for (int c = H * (N / 2) + lane0; c < (H + 1) * (N / 2); c += 64) o[c] = accbuf[N + c];
+            if (H == 0 && lane0 == 0) o[N] = accbuf[0];
+        }
+        return;
+    }
     // identity key switch (tlwe.rs:43-73): each wave sums the rows of half of the coefficients
     uint4 sum[KSQ];
     ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, H * (N / 2), (H + 1) * (N / 2), a.ksk, a.ksw, sum, lane0);

@@ -10,7 +10,7 @@ import torch
 import rustfhe_amd as R
 
 counts = [int(x) for x in sys.argv[1:]] or [1024, 2048, 8192]
-P = R.Params()
+P = R.Params(N=int(os.environ.get('RTFHE_N', '1024')))
 key0, key1, bk, ksk = R.keygen(P, 20211003)
 G = max(counts)
 rng = np.random.default_rng(0)
@@ -23,6 +23,8 @@ for name, v in (("fused", "0"), ("split", "1024")):
     os.environ["RTFHE_KS_MM_MIN"] = v
     e = R.Engine(P, 0)
     e.load_bk_torus(bk); e.load_ksk(ksk)
+    if os.environ.get("RTFHE_BACKEND") == "ntt":
+        e.set_backend(R._ffi.BACKEND_NTT_EXACT)
     engines[name] = (e, torch.empty_like(d0))
 for c in counts:
     times = {k: [] for k in engines}

@@ -412,5 +412,36 @@ def test_batch_key_switch_on_the_matrix_pipe_equals_the_fused_kernel(orc, monkey
         pick = rng.choice(1024, 6, replace=False)
         exp = np.stack([orc.gate(P, pl, orc.NAND, K.bk_f, None, ksk, c0[g], c1[g]) for g in pick])
         assert np.array_equal(b[pick], exp)
+        # the exact-integer NTT backend takes the same split path behind its own blind rotation
+        fused.set_backend(R._ffi.BACKEND_NTT_EXACT); split.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        assert np.array_equal(fused.gate_batch(R.XOR, c0[:1024], c1[:1024]), split.gate_batch(R.XOR, c0[:1024], c1[:1024]))
+    finally:
+        fused.close(); split.close()
+
+
+def test_batch_key_switch_split_path_n2048(monkeypatch):
+    """N = 2048 (config 5): both backends, whole round + remainder, fused (RTFHE_KS_MM_MIN=0) against split, word for word."""
+    import rustfhe_amd as R
+    p = R.Params(N=2048, n=48)
+    key0, key1, bk, ksk = R.keygen(p, 777)
+    monkeypatch.setenv("RTFHE_KS_MM_MIN", "0")
+    fused = R.Engine(p, 0)
+    monkeypatch.delenv("RTFHE_KS_MM_MIN")
+    split = R.Engine(p, 0)
+    try:
+        for e in (fused, split):
+            e.load_bk_torus(bk)
+            e.load_ksk(ksk)
+        rng = np.random.default_rng(48)
+        G = 1024 + 77
+        c0 = rng.integers(0, 2 ** 32, (G, p.n + 1), dtype=np.uint64).astype(np.uint32)
+        c1 = rng.integers(0, 2 ** 32, (G, p.n + 1), dtype=np.uint64).astype(np.uint32)
+        for backend in (R._ffi.BACKEND_FFT64_MIRROR, R._ffi.BACKEND_NTT_EXACT):
+            fused.set_backend(backend); split.set_backend(backend)
+            assert np.array_equal(fused.gate_batch(R.NAND, c0, c1), split.gate_batch(R.NAND, c0, c1)), backend
+        bits = rng.integers(0, 2, (2, 1024)).astype(np.uint8)
+        fused.set_backend(R._ffi.BACKEND_FFT64_MIRROR); split.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+        e0, e1 = R.encrypt_bits(p, key0, bits[0], 1), R.encrypt_bits(p, key0, bits[1], 2)
+        assert list(R.decrypt_bits(p, key0, split.gate_batch(R.NAND, e0, e1))) == list(1 - (bits[0] & bits[1]))
     finally:
         fused.close(); split.close()
