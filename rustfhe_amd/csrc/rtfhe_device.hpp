@@ -394,9 +394,11 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 // Same butterflies, same operands, same order per row as fft_forward.
 // part A: twist, pass 1, first exchange, pass 2, second exchange (issued).  part B: pass 3.  in: layout L1, out: layout L3.
 // TWIST = false: the rows come already twisted (the two-waves-per-transform kernel twists before its first, cross-wave stage).
-template <int LOGN, int NR, bool TWIST = true>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook>
 __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
-                                                    const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
+                                                    const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane,
+                                                    HOOK after_pass1 = HOOK()) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
 #pragma unroll
@@ -423,6 +425,7 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
             exchange<LOGN, 1, 2, true>(re[j], im[j], xbuf, lane, xim);
         }
     }
+    after_pass1();        // a caller's scheduling point (e.g. a priority change) between the two batched passes
     Tw<R - 1> w2;
     w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
 #pragma unroll

@@ -266,7 +266,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 }
             }
 #pragma unroll
+#ifdef HALVES_CROSS_PAIRED
             for (int m = 0; m < R; m++) { myx[lane + 64 * m] = re[m]; myx[G::XSLOTS + lane + 64 * m] = im[m]; }
+#else
+            for (int m = 0; m < R; m++) { lds_st(&myx[lane + 64 * m], re[m]); lds_st(&myx[G::XSLOTS + lane + 64 * m], im[m]); }
+#endif
             Tw<R> wt;      // untwist (times 2/N) of this half's points, from global memory: in flight across the barrier
 #pragma unroll
             for (int m = 0; m < R; m++) wt.w[m] = guntw0[(H * 8 + m) * 64 + lane];
@@ -275,7 +279,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 uint32_t* poly = accbuf + comp * N;
 #pragma unroll
                 for (int m = 0; m < R; m++) {
+#ifdef HALVES_CROSS_PAIRED
                     const double orr = otx[lane + 64 * m], oi = otx[G::XSLOTS + lane + 64 * m];
+#else
+                    const double orr = lds_ld(&otx[lane + 64 * m]), oi = lds_ld(&otx[G::XSLOTS + lane + 64 * m]);
+#endif
                     const double vr = H ? orr - re[m] : re[m] + orr;          // A: x0 + t, B: x0 - t
                     const double vi = H ? oi - im[m] : im[m] + oi;
                     // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395)

@@ -39,8 +39,9 @@
 #define PAIR_LOWER_AT 2
 #endif
 #ifndef PAIR_RAISE_AT
-#define PAIR_RAISE_AT 8
-#endif
+#define PAIR_RAISE_AT 10     // round 3 (unpaired LDS exchanges, key switch out of the kernel): raising at the END of the step instead of
+#endif                       // before barrier 2 -- side 0's inverse then runs at low priority under side 1's R + inverse -- 6.81 -> 6.67 ms
+                             // per 1024 gates (profiles/r03/pair_priority_grid.log)
 // A/B only (-DPAIR_TRIV=true -DPAIR_FIRST_ROW): the pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies
 // (fwd_stage_tw, TRIV0) and slot P's first row without its "+0.0 +".  64 fewer FP64 instructions per CMUX, same torus words --
 // and no faster (7.122 vs 7.122 ms per 1024 gates, profiles/r03/pair_lds_unpaired_reads_writes_ab.log): the kernel is not
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
 #else
         // the three digit rows side by side: twiddles loaded once per pass, a row's exchange in flight under the next rows' passes
-        fft_forward_multi_a<LOGN, L>(xr, xi, twf, myx, myx + G::XSLOTS, ln);
+        fft_forward_multi_a<LOGN, L, true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, [&]() { prio_point(1); });
         prio_point(2);
         PAIR_STAMP(1);
         fft_forward_multi_b<LOGN, L, PAIR_TRIV>(xr, xi, twf);
