@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -225,7 +226,7 @@ struct rtfhe_ctx {
     uint4* d_ksmat = nullptr;         // the key-switching key as signed byte limbs in i8-MFMA operand order (rtfhe_kernels_ksmm.hpp)
     uint32_t* d_tlwe1 = nullptr;      // lvl1 samples between the two launches of the split path
     size_t cap_tlwe1 = 0;             // in gates
-    int ks_mm_min = 1024;             // plain batches of at least this many gates take the split path (0 = never); RTFHE_KS_MM_MIN
+    int ks_mm_min = 1;                // batches of at least this many gates take the split path (0 = never: fused kernel); RTFHE_KS_MM_MIN
     bool has_bk = false, has_ksk = false;
     void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr;   // device staging for host-pointer calls
     size_t cap_a = 0, cap_b = 0, cap_c = 0;
@@ -337,21 +338,26 @@ int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
 // (the bootstrap kernel in MODE_EXTRACT, launched by `blind_rotate`), then the key switch of the whole batch as one exact i8
 // contraction on the matrix pipe (k_key_switch_mm) -- two launches back to back on the caller's stream, the lvl1 samples in between
 // stay in HBM (4 MB per 1024 gates at N = 1024).
-bool split_ok(const rtfhe_ctx* ctx, const BootstrapArgs& a, size_t full) {
-    return a.mode == MODE_GATE && !a.idx0 && ctx->d_ksmat && ctx->ks_mm_min > 0 && full >= (size_t)ctx->ks_mm_min;
+bool split_ok(const rtfhe_ctx* ctx, const BootstrapArgs& a) {
+    return a.mode == MODE_GATE && ctx->d_ksmat && ctx->ks_mm_min > 0 && (size_t)a.count >= (size_t)ctx->ks_mm_min &&
+           (size_t)a.count <= ctx->cap_tlwe1;      // (the sample buffer is sized by ensure_tlwe1 before any launch or capture)
 }
+// lvl1 sample buffer of the split path: sized outside launches (hipMalloc is not allowed inside a stream capture)
+int ensure_tlwe1(rtfhe_ctx* ctx, size_t gates) {
+    if (ctx->cap_tlwe1 >= gates) return 0;
+    HIPCHECK(ctx, hipDeviceSynchronize());            // earlier launches may still read the old buffer
+    if (ctx->d_tlwe1) HIPCHECK(ctx, hipFree(ctx->d_tlwe1));
+    ctx->d_tlwe1 = nullptr; ctx->cap_tlwe1 = 0;
+    const size_t cap = gates < 8192 ? 8192 : gates;
+    HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tlwe1, cap * ((size_t)ctx->p.N + 1) * 4));
+    ctx->cap_tlwe1 = cap;
+    return 0;
+}
+// blind_rotate(ctx, a', s) launches the bootstrap kernel(s) of the whole batch with a'.mode = MODE_EXTRACT: every gate's lvl1 sample goes to
+// a'.ext (segments of a batch advance it by N + 1 words per gate) and its output row is zeroed for the key switch's atomics
 template <typename F>
 int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate) {
-    const size_t count = (size_t)a.count, N = (size_t)ctx->p.N;
-    if (ctx->cap_tlwe1 < count) {        // grows outside the steady state only (never inside a stream capture: netlist waves are fused)
-        if (ctx->d_tlwe1) HIPCHECK(ctx, hipFree(ctx->d_tlwe1));
-        ctx->d_tlwe1 = nullptr; ctx->cap_tlwe1 = 0;
-        const size_t cap = count < 8192 ? 8192 : count;
-        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tlwe1, cap * (N + 1) * 4));
-        ctx->cap_tlwe1 = cap;
-    }
-    uint32_t* final_out = a.out;
-    a.mode = MODE_EXTRACT; a.out = ctx->d_tlwe1;
+    a.mode = MODE_EXTRACT; a.ext = ctx->d_tlwe1;
     if (int rc = blind_rotate(ctx, a, s)) return rc;
     const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 63) / 64;
     // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
@@ -364,8 +370,7 @@ int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate)
         ctx->ks_events_used += 2;
         HIPCHECK(ctx, hipEventRecord(ev_a, s));
     }
-    HIPCHECK(ctx, hipMemsetAsync(final_out, 0, count * ((size_t)ctx->p.n + 1) * 4, s));
-    KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, final_out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk};
+    KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, a.out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk, a.ops, a.idx0, a.idx1, a.idx_out, a.num_wires};
     hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
     HIPCHECK(ctx, hipGetLastError());
     if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
@@ -420,10 +425,17 @@ int launch_bootstrap_halves11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) 
     return 0;
 }
 
+// words per gate of the output buffer, by mode (MODE_EXTRACT: the final TLWE rows; the lvl1 samples go to `ext`)
+size_t mode_out_words(const BootstrapArgs& a, int N) {
+    return a.mode == MODE_BLIND_ROTATE ? (size_t)2 * N : (size_t)a.n + 1;
+}
+
+
 // `cnt` gates of a batch starting at gate `off` (plain batches advance the ciphertext pointers, netlist waves the index arrays)
-BootstrapArgs batch_segment(BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
+BootstrapArgs batch_segment(const rtfhe_ctx* ctx, BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
     if (a.idx0) { a.ops += off; a.idx0 += off; a.idx1 += off; a.idx_out += off; }
     else { a.in0 += off * ((size_t)a.n + 1); a.in1 += off * ((size_t)a.n + 1); a.out += off * out_words; }
+    if (a.ext) a.ext += off * ((size_t)ctx->p.N + 1);
     a.count = (int32_t)cnt;
     return a;
 }
@@ -444,15 +456,14 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         if (force == 2) return launch_bootstrap_pair10(ctx, a, s);
         if (force == 8) return launch_bootstrap_w<10, 8>(ctx, a, s);
         if (force == 4) return launch_bootstrap_w<10, 4>(ctx, a, s);
-        const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * (1 << LOGN) : (size_t)a.n + 1;
+        if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_t<10>);     // comes back here in MODE_EXTRACT
+        const size_t out_words = mode_out_words(a, 1 << LOGN);
         const size_t round = (size_t)4 * ctx->num_cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
-        if (full) {
-            if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_pair10)
-                                                : launch_bootstrap_pair10(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
-        }
+        if (full)
+            if (int rc = launch_bootstrap_pair10(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
         if (rem) {
-            const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+            const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
             if (rem <= (size_t)ctx->wg_max) return launch_bootstrap_wg10(ctx, tail, s);
             if (rem <= (size_t)2 * ctx->num_cus) return launch_bootstrap_pair10_g<2>(ctx, tail, s);
             if (rem <= (size_t)3 * ctx->num_cus) return launch_bootstrap_pair10_g<3>(ctx, tail, s);
@@ -465,14 +476,14 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         if (!(ctx->d_htw && ctx->d_hbk) || ctx->force_waves == 4) return launch_bootstrap_w<11, 4>(ctx, a, s);
         // whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU
         // (a gate's two waves then share their SIMDs with fewer other waves: a single gate takes 0.67 x a full round)
-        const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * (1 << LOGN) : (size_t)a.n + 1;
+        if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_t<11>);
+        const size_t out_words = mode_out_words(a, 1 << LOGN);
         const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
         if (full)
-            if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_halves11_g<4>)
-                                                : launch_bootstrap_halves11_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+            if (int rc = launch_bootstrap_halves11_g<4>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
         if (!rem) return 0;
-        const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+        const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
         if (rem <= cus) return launch_bootstrap_halves11_g<1>(ctx, tail, s);
         if (rem <= 2 * cus) return launch_bootstrap_halves11_g<2>(ctx, tail, s);
         if (rem <= 3 * cus) return launch_bootstrap_halves11_g<3>(ctx, tail, s);
@@ -618,14 +629,14 @@ int launch_bootstrap_ntt_wg(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
 // workgroup (one workgroup per CU): with fewer gates per CU a gate's two waves share their SIMDs with fewer other waves -- a
 // circuit wave of 1-3 gates takes 0.67 x the time of a full round instead of all of it.
 int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * ntt::N : (size_t)a.n + 1;
+    if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_ntt_pair);
+    const size_t out_words = mode_out_words(a, ntt::N);
     const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
     if (full)
-        if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_ntt_pair_g<4>)
-                                            : launch_bootstrap_ntt_pair_g<4>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (int rc = launch_bootstrap_ntt_pair_g<4>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
-    const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+    const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
     if (rem <= cus) return ctx->force_waves == 2 ? launch_bootstrap_ntt_pair_g<1>(ctx, tail, s) : launch_bootstrap_ntt_wg(ctx, tail, s);
     if (rem <= 2 * cus) return launch_bootstrap_ntt_pair_g<2>(ctx, tail, s);
     if (rem <= 3 * cus) return launch_bootstrap_ntt_pair_g<3>(ctx, tail, s);
@@ -649,14 +660,14 @@ int launch_bootstrap_ntt_halves_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s
 #define NTT_HALVES_ROUND 4
 #endif
 int launch_bootstrap_ntt_halves(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    const size_t out_words = a.mode == MODE_BLIND_ROTATE ? (size_t)2 * 2048 : (size_t)a.n + 1;
+    if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_ntt_halves);
+    const size_t out_words = mode_out_words(a, 2048);
     const size_t cus = (size_t)ctx->num_cus, round = NTT_HALVES_ROUND * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
     if (full)
-        if (int rc = split_ok(ctx, a, full) ? launch_split(ctx, batch_segment(a, 0, full, out_words), s, launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>)
-                                            : launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>(ctx, batch_segment(a, 0, full, out_words), s)) return rc;
+        if (int rc = launch_bootstrap_ntt_halves_g<NTT_HALVES_ROUND>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
-    const BootstrapArgs tail = batch_segment(a, full, rem, out_words);
+    const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
     if (rem <= cus || NTT_HALVES_ROUND == 1) return launch_bootstrap_ntt_halves_g<1>(ctx, tail, s);
     if (rem <= 2 * cus || NTT_HALVES_ROUND == 2) return launch_bootstrap_ntt_halves_g<2>(ctx, tail, s);
     if (rem <= 3 * cus || NTT_HALVES_ROUND == 3) return launch_bootstrap_ntt_halves_g<3>(ctx, tail, s);
@@ -678,6 +689,14 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.ops = d_ops; a.idx0 = d_idx0; a.idx1 = d_idx1; a.idx_out = d_idx_out;
     a.num_wires = num_wires; a.fault = ctx->d_fault;
     a.dbg = ctx->d_dbg;
+    a.ext = nullptr;
+    if (mode == MODE_GATE && ctx->ks_mm_min > 0 && ctx->d_ksmat && count > ctx->cap_tlwe1) {
+        // the split path's sample buffer grows here, outside any stream capture (inside one the batch stays on the fused kernel)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs == hipStreamCaptureStatusNone)
+            if (int rc = ensure_tlwe1(ctx, count)) return rc;
+    }
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
         if (int rc = ntt_prepare(ctx)) return rc;
         // two waves per gate: 11.5 ms per 1024 gates vs 13.3 ms one wave per gate in 4-wave workgroups (RTFHE_FORCE_WAVES=4);
@@ -1181,6 +1200,7 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
         hipLaunchKernelGGL((k_ksmat_build<8, 2>), dim3(4096), dim3(256), 0, ctx->stream, m);
         HIPCHECK(ctx, hipGetLastError());
         HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (int rc = ensure_tlwe1(ctx, 8192)) return rc;
     }
     ctx->has_ksk = true;
     for (rtfhe_ctx* peer : ctx->peers) {
@@ -1243,6 +1263,11 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
         return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_create needs device pointers (got memory the GPU cannot address)");
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT)
         if (int rc = ntt_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
+    if (ctx->ks_mm_min > 0 && ctx->d_ksmat) {              // ... so the split path's sample buffer is sized for the largest wave now
+        size_t widest = 0;
+        for (int32_t w = 0; w < num_waves; w++) widest = std::max(widest, (size_t)(wave_offsets[w + 1] - wave_offsets[w]));
+        if (int rc = ensure_tlwe1(ctx, widest)) return rc;
+    }
     rtfhe_circuit* c = new (std::nothrow) rtfhe_circuit();
     if (!c) return fail(ctx, RTFHE_ERR_NOMEM, "out of host memory");
     c->ctx = ctx; c->device = ctx->device; c->waves = num_waves;

@@ -16,7 +16,7 @@ namespace rtfhe {
 
 enum { OP_NAND = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3, OP_NOT = 4, OP_COPY = 5, OP_ANDNY = 6 };
 enum { MODE_GATE = 0, MODE_BLIND_ROTATE = 1,
-       MODE_EXTRACT = 2 };   // blind rotate + sample extract, out = lvl1 samples [count][N+1] for the batch key switch (rtfhe_kernels_ksmm.hpp)
+       MODE_EXTRACT = 2 };   // blind rotate + sample extract into `ext`, for the batch key switch that follows (rtfhe_kernels_ksmm.hpp)
 
 struct BootstrapArgs {
     const cplx* tw;          // [Geo::TW_TOTAL] forward table then inverse table
@@ -24,7 +24,9 @@ struct BootstrapArgs {
     const uint32_t* ksk;     // device layout [N*(t/2)*(base^2-1) + 1][ksw] (pairs of levels pre-summed, see ks_accumulate); last row all zero
     const uint32_t* in0;     // [count][n+1]
     const uint32_t* in1;     // [count][n+1] (may alias in0)
-    uint32_t* out;           // MODE_GATE: [count][n+1];  MODE_BLIND_ROTATE: [count][2][N];  MODE_EXTRACT: [count][N+1]
+    uint32_t* out;           // MODE_GATE / MODE_EXTRACT: [count][n+1] (or the wire table);  MODE_BLIND_ROTATE: [count][2][N]
+    uint32_t* ext;           // MODE_EXTRACT: lvl1 samples [count][N+1] (a'[0..N), b'), row = gate number within the launch; the gate's
+                             // `out` row is ZEROED (the batch key switch adds its K-slices into it with wrapping atomics)
     int32_t count;
     int32_t op;
     int32_t n;

@@ -29,9 +29,13 @@ namespace rtfhe {
 struct KsMmArgs {
     const uint32_t* tlwe1;   // [count][N+1]: extracted lvl1 samples a'[0..N), b'
     const uint4* kmat;       // [colgroups][N/2 K-steps][4 limbs][64 lanes] x 16 B
-    uint32_t* out;           // [count][n+1], ZERO on entry: every K-slice adds its part with a wrapping atomic (order-free in u32)
+    uint32_t* out;           // row g (plain batch) or row idx_out[g] (netlist wave) of [..][n+1]; ZERO on entry (the extract launch
+                             // zeroes it): every K-slice adds its part with a wrapping atomic (order-free in u32)
     int32_t count, n, N, colgroups;
     int32_t splitk;          // K-slices per (gate group, column group): N/4 must be divisible by 4 * splitk
+    // netlist wave (all null for a plain batch): the same validity rule as gate_io -- a gate the bootstrap launch skipped is skipped here
+    const int32_t* ops; const int32_t* idx0; const int32_t* idx1; const int32_t* idx_out;
+    int32_t num_wires;
 };
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -112,9 +116,16 @@ __global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
         for (int r = 0; r < 4; r++) {
             const int g = (mg * MT + mt) * 16 + 4 * q + r;
             if (g >= a.count) continue;
+            size_t row = (size_t)g;
+            if (a.idx_out) {
+                const int i0 = a.idx0[g], i1 = a.idx1[g], o = a.idx_out[g];
+                const unsigned nw = (unsigned)a.num_wires;
+                if (!((unsigned)i0 < nw && (unsigned)i1 < nw && (unsigned)o < nw && (unsigned)a.ops[g] <= (unsigned)OP_ANDNY)) continue;
+                row = (size_t)o;
+            }
             const uint32_t s = (uint32_t)acc[mt][0][r] + ((uint32_t)acc[mt][1][r] << 8) + ((uint32_t)acc[mt][2][r] << 16) + ((uint32_t)acc[mt][3][r] << 24);
             const uint32_t bprime = (col == a.n && slice == 0) ? a.tlwe1[(size_t)g * w1 + a.N] : 0u;
-            atomicAdd(a.out + (size_t)g * ((size_t)a.n + 1) + col, bprime - s);
+            atomicAdd(a.out + row * ((size_t)a.n + 1) + col, bprime - s);
         }
     }
 }

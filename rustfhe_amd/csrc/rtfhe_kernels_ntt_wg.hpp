@@ -178,6 +178,13 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_ntt_wg(const NttBootstrapA
         accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[k] : (0u - av[k]);
     }
     __syncthreads();
+    if (a.mode == MODE_EXTRACT) {      // the key switch of the whole batch follows as its own launch (k_key_switch_mm)
+        uint32_t* o = a.ext + (size_t)g * (N + 1);
+        for (int c = tid; c < N; c += 64 * NW) o[c] = accbuf[N + c];
+        if (tid == 0) o[N] = bprime;
+        for (int c = tid; c <= n; c += 64 * NW) io.out[c] = 0u;
+        return;
+    }
     // key switch: wave w sums the rows of coefficients [w N/8, (w+1) N/8); partial sums meet in LDS
     uint4 sum[KSQ];
     ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, wave * (N / NW), (wave + 1) * (N / NW), a.ksk, a.ksw, sum, lane);
