@@ -10,7 +10,8 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out", "profiles_" + tag)
 os.makedirs(dst, exist_ok=True)
-summary = {"tag": tag, "kernels": {}, "pmc": {}}
+summary = {"tag": tag, "kernels": {}, "pmc": {}, "pmc_key_switch_mm": {}}
+DOM = os.environ.get("RTFHE_PROF_KERNEL", "k_bootstrap_pair")     # the dominant kernel the roofline is about
 
 for f in glob.glob(os.path.join(out_dir, "kt", "**", "*kernel_stats.csv"), recursive=True):
     with open(f) as fh:
@@ -23,25 +24,31 @@ for f in glob.glob(os.path.join(out_dir, "kt", "**", "*kernel_stats.csv"), recur
 for f in glob.glob(os.path.join(out_dir, "kt", "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if "k_bootstrap" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if DOM in r["Kernel_Name"]]
+    k2 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if "k_key_switch_mm" in r["Kernel_Name"]]
+    if k2:
+        summary["k_key_switch_mm_launch_ns"] = k2
     if d:
         summary["k_bootstrap_launch_ns"] = d
-        r0 = [r for r in rows if "k_bootstrap" in r["Kernel_Name"]][0]
+        r0 = [r for r in rows if DOM in r["Kernel_Name"]][0]
         summary["k_bootstrap_resources"] = {k: r0.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
 
 for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
-    acc = {}
+    acc, acc2 = {}, {}
     for r in rows:
-        if "k_bootstrap" not in r.get("Kernel_Name", ""):
-            continue
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if DOM in r.get("Kernel_Name", ""):
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        elif "k_key_switch_mm" in r.get("Kernel_Name", ""):
+            acc2.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in acc.items():
         summary["pmc"][k] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
+    for k, v in acc2.items():
+        summary["pmc_key_switch_mm"][k] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
     # effective clock of the kernel (MI355X_MICROARCH.md, DVFS section): GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / launch duration,
     # per launch with the counter pass's own timestamps when the CSV carries them
-    g = [r for r in rows if "k_bootstrap" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "GRBM_GUI_ACTIVE"]
+    g = [r for r in rows if DOM in r.get("Kernel_Name", "") and r.get("Counter_Name") == "GRBM_GUI_ACTIVE"]
     if g and "Start_Timestamp" in g[0] and "End_Timestamp" in g[0]:
         clk = sorted(float(r["Counter_Value"]) / 8.0 / max(1, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in g)
         summary["effective_clock_GHz"] = {"median": round(clk[len(clk) // 2], 3), "min": round(clk[0], 3), "max": round(clk[-1], 3),
@@ -53,7 +60,7 @@ for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv
 # was measured on (copy it to profiles/pmc_traffic.json together with the summary).
 sys.path.insert(0, root)
 import bench  # noqa: E402  (launcher half only: no torch, no HIP)
-names = [k for k in summary["kernels"] if "k_bootstrap" in k]
+names = [k for k in summary["kernels"] if DOM in k]
 if "FETCH_SIZE" in summary["pmc"] and "WRITE_SIZE" in summary["pmc"] and names:
     fetch_kb, write_kb = summary["pmc"]["FETCH_SIZE"]["per_launch_mean"], summary["pmc"]["WRITE_SIZE"]["per_launch_mean"]
     gates = int(os.environ.get("RTFHE_PROF_GATES", "1024"))
@@ -61,6 +68,9 @@ if "FETCH_SIZE" in summary["pmc"] and "WRITE_SIZE" in summary["pmc"] and names:
         "gates_per_launch": gates, "kernel": names[0].split("<")[0].split("::")[-1],
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
         "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb, "src_hash": bench.kernel_src_hash(),
+        "key_switch_mm_hbm_bytes_per_launch": (int(2 * summary["pmc_key_switch_mm"]["FETCH_SIZE"]["per_launch_mean"] * 1024 +
+                                                   summary["pmc_key_switch_mm"]["WRITE_SIZE"]["per_launch_mean"] * 1024)
+                                               if "FETCH_SIZE" in summary["pmc_key_switch_mm"] and "WRITE_SIZE" in summary["pmc_key_switch_mm"] else None),
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 reports 1/2 of 16B/lane coalesced reads); WRITE_SIZE exact; "
                 "separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline`, mean over all its launches",
         "source": "profiles/%s/summary.json" % tag,
