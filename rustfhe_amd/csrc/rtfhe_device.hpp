@@ -394,8 +394,42 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 // Same butterflies, same operands, same order per row as fft_forward.
 // part A: twist, pass 1, first exchange, pass 2, second exchange (issued).  part B: pass 3.  in: layout L1, out: layout L3.
 // TWIST = false: the rows come already twisted (the two-waves-per-transform kernel twists before its first, cross-wave stage).
+// The two halves of the N = 1024 geometry's affine exchange as separate calls (see exchange<>: slot = base(lane) + stride * m), so that a caller
+// can place the 16 writes and the two groups of 8 reads between blocks of arithmetic instead of issuing 32 DS instructions in one burst (a wave's
+// LDS queue holds 16: a burst stalls the wave at issue, and with it its FP64 stream).
+template <int LOGN, int FROM, int TO>
+struct XAffine {
+    typedef Geo<LOGN> G;
+    static_assert(G::LR == G::LOW, "N = 1024 geometry");
+    static constexpr int R = G::R;
+    static constexpr bool X12 = (FROM + TO == 3);
+    __device__ __forceinline__ static int base(int layout, int lane) {
+        return layout == 1 ? lane : layout == 2 ? (G::NLOW + 64) * (lane >> G::LOW) + (lane & (G::NLOW - 1)) : (R + 1) * lane;
+    }
+    __host__ __device__ static constexpr int stride(int layout) { return layout == 1 ? 64 + G::NLOW : layout == 2 ? (X12 ? G::NLOW : G::NLOW + 1) : 1; }
+    __device__ __forceinline__ static void write(const double (&re)[R], const double (&im)[R], double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
+        const int bw = base(FROM, lane);
+        constexpr int sw = stride(FROM);
+#pragma unroll
+        for (int m = 0; m < R; m++) lds_st(&xbuf[bw + sw * m], re[m]);
+#pragma unroll
+        for (int m = 0; m < R; m++) lds_st(&xim[bw + sw * m], im[m]);
+    }
+    // HALF 0: the operands of the next pass's first two butterflies (m = 0, 1 with m + R/2), HALF 1: of the other two
+    template <int HALF>
+    __device__ __forceinline__ static void read_half(double (&re)[R], double (&im)[R], const double* __restrict__ xbuf, const double* __restrict__ xim, int lane) {
+        const int br = base(TO, lane);
+        constexpr int sr = stride(TO);
+#pragma unroll
+        for (int m = HALF * (R / 4); m < (HALF + 1) * (R / 4); m++) {
+            re[m] = lds_ld(&xbuf[br + sr * m]); re[m + R / 2] = lds_ld(&xbuf[br + sr * (m + R / 2)]);
+            im[m] = lds_ld(&xim[br + sr * m]);  im[m + R / 2] = lds_ld(&xim[br + sr * (m + R / 2)]);
+        }
+    }
+};
+
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook>
+template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook, bool INTERLEAVE = false>
 __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
                                                     const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane,
                                                     HOOK after_pass1 = HOOK()) {
@@ -416,6 +450,48 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
                 im[j][k] = ic + rs;
             }
     }
+  if constexpr (INTERLEAVE) {
+    // Interleaved form (N = 1024, R = 8): a row's 16 exchange writes follow its pass; its 16 reads are issued in two groups of 8 BETWEEN the three
+    // stages of the NEXT row's pass (the last row's between the stages of the next pass's first row), each group pinned by scheduling barriers.  No
+    // burst is longer than 16 DS instructions and every read has a stage of arithmetic to land under.
+    // Measured: k_bootstrap_pair 6.73 -> 6.69 ms per 1024 gates; the N = 2048 kernel, whose waves also meet at barriers inside a step, 17.13 -> 17.39
+    // (slower): on by template argument where it pays.
+    static_assert(G::LR == 3, "three stages per pass");
+    typedef XAffine<LOGN, 1, 2> X1;
+    typedef XAffine<LOGN, 2, 3> X2;
+    auto pass = [&](int j, const cplx* w, auto&& between0, auto&& between1) {
+        fwd_stage_tw<R, 2>(re[j], im[j], w + (R - 8));
+        __builtin_amdgcn_sched_barrier(0); between0(); __builtin_amdgcn_sched_barrier(0);
+        fwd_stage_tw<R, 1>(re[j], im[j], w + (R - 4));
+        __builtin_amdgcn_sched_barrier(0); between1(); __builtin_amdgcn_sched_barrier(0);
+        fwd_stage_tw<R, 0>(re[j], im[j], w + (R - 2));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto nothing = [] {};
+    Tw<R - 1> w1;
+    w1.load(tw + G::TW_P1 + lane, 64);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        if (j == 0) pass(0, w1.w, nothing, nothing);
+        else pass(j, w1.w, [&] { X1::template read_half<0>(re[j - 1], im[j - 1], xbuf, xim, lane); }, [&] { X1::template read_half<1>(re[j - 1], im[j - 1], xbuf, xim, lane); wave_lds_sync(); });
+        X1::write(re[j], im[j], xbuf, xim, lane);
+        wave_lds_sync();
+    }
+    after_pass1();
+    Tw<R - 1> w2;
+    w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
+    // the last row of the first exchange is read under pass 2 of row 0 -- but row 0's own pass-2 inputs were read long ago
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        if (j == 0) pass(0, w2.w, [&] { X1::template read_half<0>(re[NR - 1], im[NR - 1], xbuf, xim, lane); }, [&] { X1::template read_half<1>(re[NR - 1], im[NR - 1], xbuf, xim, lane); wave_lds_sync(); });
+        else pass(j, w2.w, [&] { X2::template read_half<0>(re[j - 1], im[j - 1], xbuf, xim, lane); }, [&] { X2::template read_half<1>(re[j - 1], im[j - 1], xbuf, xim, lane); wave_lds_sync(); });
+        X2::write(re[j], im[j], xbuf, xim, lane);
+        wave_lds_sync();
+    }
+    X2::template read_half<0>(re[NR - 1], im[NR - 1], xbuf, xim, lane);
+    X2::template read_half<1>(re[NR - 1], im[NR - 1], xbuf, xim, lane);
+    wave_lds_sync();
+  } else {
     {
         Tw<R - 1> w1;
         w1.load(tw + G::TW_P1 + lane, 64);
@@ -433,6 +509,7 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
         P12<R, G::LR - 1>::fwd(re[j], im[j], w2.w);
         exchange<LOGN, 2, 3, true>(re[j], im[j], xbuf, lane, xim);
     }
+  }
 }
 template <int LOGN, int NR, bool TRIV = false>
 __device__ __forceinline__ void fft_forward_multi_b(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],

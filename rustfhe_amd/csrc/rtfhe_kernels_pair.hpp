@@ -64,6 +64,21 @@ __device__ __forceinline__ void lds_barrier() {
 
 // the first row of a fold: the reference adds it to FrrSeries::zero() (trgsw.rs:290-299); +0.0 + x == x for every x except that
 // it turns a -0.0 into +0.0, and the sign of a zero never reaches a torus word (see fwd_stage_tw in rtfhe_device.hpp)
+// A/B only (-DPAIR_FLAG_SYNC): synchronisation of the TWO waves of one gate only.  s_barrier is workgroup-wide although the four gates of a
+// workgroup share nothing after start-up; the phase stamps show BOTH sides of a pair ~1.1 k cycles "at barrier 1", which looked like the pairs
+// waiting for the slowest gate.  Here each side publishes an arrival counter in LDS after its hand-off stores and polls its partner's (DS
+// instructions of a wave execute in order, so a partner that sees counter >= k also sees the stores issued before it; no fence, which would wait
+// for the key rows in flight).  Identical outputs -- and no faster: 6.76 vs 6.74 ms per 1024 gates, 4.34 vs 4.37 at 512, 6.14 vs 6.20 at 768
+// (profiles/r03/pair_flag_sync_ab.log).  The time at the barrier is the side's own hand-off stores draining, not skew between gates.
+__device__ __forceinline__ void pair_sync(unsigned my_flag_addr, unsigned partner_flag_addr, unsigned k) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(my_flag_addr), "v"(k) : "memory");
+    unsigned v;
+    do {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(partner_flag_addr) : "memory");
+        v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    } while ((int)(v - k) < 0);
+}
+
 template <int R>
 __device__ __forceinline__ void mac_row_first(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
 #pragma unroll
@@ -90,7 +105,8 @@ struct PairLds {
     static constexpr size_t TW = (size_t)G::TW_TOTAL * sizeof(cplx);
     static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers
     static_assert(XB >= (size_t)G::P * sizeof(cplx), "an exchange buffer pair must hold one spectrum");
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * G::N * 4 + (size_t)npad * 4 + 2 * XB; }
+    static constexpr size_t FLAGS = 16;       // two arrival counters per gate (pair_sync), 16-byte aligned tail of the gate's region
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * G::N * 4 + (size_t)npad * 4 + 2 * XB + FLAGS; }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
@@ -121,6 +137,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);
     uint32_t* abar = accbuf + 2 * N;
     double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + (size_t)a.npad * 4);
+    // arrival counters of the pair (zeroed before the start-up barrier)
+    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + PairLds::gate_bytes(a.npad) - PairLds::FLAGS);
+    if (lane == 0) flags[side] = 0u;
+    [[maybe_unused]] const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side);
+    [[maybe_unused]] const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side));
     double* xb1 = xb0 + 2 * G::XSLOTS;
     double* myx = side ? xb1 : xb0;
     cplx* hand0 = reinterpret_cast<cplx*>(xb0) + lane;    // [R][64] cplx
@@ -245,7 +266,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
 #else
         // the three digit rows side by side: twiddles loaded once per pass, a row's exchange in flight under the next rows' passes
-        fft_forward_multi_a<LOGN, L, true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, [&]() { prio_point(1); });
+        auto pp1 = [&]() { prio_point(1); };
+#ifdef PAIR_NO_INTERLEAVE     // A/B: the exchanges' DS instructions in bursts, as the compiler places them
+        fft_forward_multi_a<LOGN, L, true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
+#else
+        fft_forward_multi_a<LOGN, L, true, decltype(pp1), true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
+#endif
         prio_point(2);
         PAIR_STAMP(1);
         fft_forward_multi_b<LOGN, L, PAIR_TRIV>(xr, xi, twf);
@@ -281,7 +307,15 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
         prio_point(6);
         PAIR_STAMP(4);
+#ifdef PAIR_WG_BARRIER     // A/B: the workgroup-wide barrier of rounds 1-2
+#ifdef PAIR_FLAG_SYNC
+        pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u);
+#else
         lds_barrier();
+#endif
+#else
+        pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u);
+#endif
         prio_point(7);
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
