@@ -42,8 +42,12 @@ FP64_VALU_PEAK = CUS * SIMDS_PER_CU * DP_LANES_PER_CLK * CLOCK_HZ     # 39.32e12
 
 def dp_wave_instr_per_cmux(N=1024, l=3):
     """FP64-rate VALU wave-instructions one CMUX step costs, derived from the transform structure of
-    rustfhe_amd/csrc/rtfhe_device.hpp (checked against the built kernel's ISA by tests/test_dp_opcount.py):
-    the mirror arithmetic may not fuse, so every product and every sum is one v_mul_f64 / v_add_f64."""
+    rustfhe_amd/csrc/rtfhe_device.hpp (checked against the built kernel's ISA by tests/test_bench_launcher.py):
+    the mirror arithmetic may not fuse, so every product and every sum is one v_mul_f64 / v_add_f64.
+    `reference` is the reference's operation list; the kernels execute `total` = reference minus the instructions that cannot change a
+    torus word: the 6 multiplies / sums of the one butterfly per transform whose twiddle is exactly (1, 0) (N = 1024: the halfnn = 4
+    stage of every 512-point transform; N = 2048: of both 512-point halves) and, in the two-waves-per-gate kernel at N = 1024, the
+    "+0.0 +" of the first row of component 0's fold."""
     P = N // 2
     R = P // 64                               # points per lane
     LR = R.bit_length() - 1
@@ -57,7 +61,11 @@ def dp_wave_instr_per_cmux(N=1024, l=3):
     trunc_add = 2 * R                         # the magic-constant add of trunc_to_torus, per inverse transform
     arith = 2 * l * transform + 2 * transform + 2 * 2 * l * mac + 2 * trunc_add
     cvt = 2 * l * 2 * R + 2 * 2 * R           # v_cvt_f64_i32 per digit, v_trunc_f64 per output word
-    return {"add_mul": arith, "cvt_trunc": cvt, "total": arith + cvt, "transform": transform, "mac_row": mac}
+    transforms = 2 * l + 2
+    unit = 6 * transforms * (1 if N == 1024 else 2)               # per 512-point (sub-)transform: 4 products + 2 sums
+    first_row = 2 * R if N == 1024 else 0                         # slot P of side 0 only
+    return {"add_mul": arith - unit - first_row, "cvt_trunc": cvt, "total": arith - unit - first_row + cvt, "reference": arith + cvt,
+            "transform": transform, "unit_twiddle_saved_per_transform": 6 * (1 if N == 1024 else 2), "first_row_saved": first_row, "mac_row": mac}
 
 
 def ntt_dp_wave_instr_per_cmux(N=1024, l=3):

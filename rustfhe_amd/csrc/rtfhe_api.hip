@@ -760,7 +760,18 @@ int launch_permute_t(rtfhe_ctx* ctx, const double* src, double* dst, size_t coun
     return 0;
 }
 
+// The bootstrap kernels skip the multiplies of the butterfly whose twiddle is the first entry of the halfnn = 4 stage (BOOT_TRIV,
+// rtfhe_device.hpp): that entry must be exactly (1, +-0) -- cos(0), sin(0), which every libm returns exactly and every table the reference's
+// builders produce holds.  A table imported through rtfhe_set_twiddles is checked here and refused otherwise.
+bool unit_twiddles_ok(const HostTw& tw) {
+    auto is_zero = [](double v) { return v == 0.0; };
+    return tw.fwd_c[tw.fwd_off(4)] == 1.0 && is_zero(tw.fwd_s[tw.fwd_off(4)]) && tw.inv_c[tw.inv_off(4)] == 1.0 && is_zero(tw.inv_s[tw.inv_off(4)]);
+}
+
 int upload_twiddles(rtfhe_ctx* ctx) {
+    if (BOOT_TRIV && !unit_twiddles_ok(ctx->tw))
+        return fail(ctx, RTFHE_ERR_INVALID, "twiddle table: the first entry of the halfnn = 4 stage must be exactly (1, 0) in both directions "
+                                            "(cos 0, sin 0: true of every table the reference builds)");
     std::vector<cplx> t = ctx->logn == 10 ? ctx->tw.device_table<10>() : ctx->tw.device_table<11>();
     if (!ctx->d_tw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tw, t.size() * sizeof(cplx)));
     HIPCHECK(ctx, hipMemcpy(ctx->d_tw, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice));
@@ -1099,9 +1110,10 @@ int rtfhe_get_twiddles(const rtfhe_ctx* ctx, double* ifft_table, double* fft_tab
 int rtfhe_set_twiddles(rtfhe_ctx* ctx, const double* ifft_table, const double* fft_table) {
     if (int rc = use(ctx)) return rc;
     if (!ifft_table || !fft_table) return fail(ctx, RTFHE_ERR_INVALID, "null argument");
+    const HostTw before = ctx->tw;
     ctx->tw.import_ref(ifft_table, fft_table);
     HIPCHECK(ctx, hipDeviceSynchronize());
-    if (int rc = upload_twiddles(ctx)) return rc;
+    if (int rc = upload_twiddles(ctx)) { ctx->tw = before; return rc; }      // a refused table leaves the context as it was
     // a key loaded in torus form was transformed with the old tables: redo it (spectra loaded through rtfhe_load_bk_fft
     // are the caller's and stay as they are)
     if (ctx->has_bk && ctx->d_bk_torus)

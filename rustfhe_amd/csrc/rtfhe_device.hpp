@@ -20,6 +20,14 @@ namespace rtfhe {
 
 typedef double2 cplx;  // .x = re / cos, .y = im / sin
 
+// The bootstrap kernels (outputs = torus words) skip the multiplies of the one butterfly per transform whose twiddle is exactly (1, 0) and the
+// "+0.0 +" of a fold's first row -- see fwd_stage_tw (TRIV0) for why no torus word can change; the host refuses a twiddle table whose entry is
+// not exactly (1, +-0) (check_unit_twiddles, rtfhe_api.hip).  -DRTFHE_BOOT_TRIV=0: the reference's operation list as it stands (A/B builds).
+#ifndef RTFHE_BOOT_TRIV
+#define RTFHE_BOOT_TRIV 1
+#endif
+constexpr bool BOOT_TRIV = RTFHE_BOOT_TRIV != 0;
+
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 // Geometry of the N/2-point transform on one wavefront.
@@ -380,12 +388,12 @@ __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double
     exchange<LOGN, 2, 3, DUAL>(re, im, xbuf, lane, xim);
     P3<G::R, G::NLOW, G::LOW - 1, TRIV>::fwd(re, im, w3.w);
 }
-template <int LOGN, bool DUAL = false>
+template <int LOGN, bool DUAL = false, bool TRIV = false>
 __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                             const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
                                             double* __restrict__ xim = nullptr) {
     fft_forward_a<LOGN, DUAL>(re, im, tw, xbuf, lane, xim);
-    fft_forward_b<LOGN, DUAL>(re, im, tw, xbuf, lane, xim);
+    fft_forward_b<LOGN, DUAL, TRIV>(re, im, tw, xbuf, lane, xim);
 }
 
 // NR forward transforms side by side in one wave (the digit rows of one polynomial): every pass loads its twiddles ONCE for
@@ -546,11 +554,11 @@ __device__ __forceinline__ void fft_forward_mid(double (&re)[Geo<LOGN>::R], doub
     wave_lds_sync();
     P12<R, G::LR - 1>::fwd(re, im, w2.w);
 }
-template <int LOGN>
+template <int LOGN, bool TRIV = false>
 __device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
                                                  double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
     fft_forward_mid<LOGN>(re, im, tw, xbuf, xim, lane);
-    fft_forward_b<LOGN, true>(re, im, tw, xbuf, lane, xim);
+    fft_forward_b<LOGN, true, TRIV>(re, im, tw, xbuf, lane, xim);
 }
 
 // Inverse transform.  in: layout L3, unscaled (the 2/N factor lives in the untwist twiddles).  out: layout L1, untwisted (natural

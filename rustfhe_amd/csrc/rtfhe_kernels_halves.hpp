@@ -219,7 +219,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #ifndef HALVES_FETCH_LATE
             fetch(bA, i, h * 2 * L);                    // (row 0, comp 0) of this polynomial: in flight under the last pass
 #endif
-            fft_forward_multi_b<10, L>(yr, yi, tw_sub);
+            fft_forward_multi_b<10, L, BOOT_TRIV>(yr, yi, tw_sub);
 #ifdef HALVES_FETCH_LATE
             fetch(bA, i, h * 2 * L);
 #endif
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1;
                 w1.load(gip10 + lane, 64);                  // global memory: requested first, used last
                 w3.load(twi_small + G::TW_P3, 1);
-                P3<R, G::NLOW, G::LOW - 1>::inv(re, im, w3.w);
+                P3<R, G::NLOW, G::LOW - 1, BOOT_TRIV>::template inv<false>(re, im, w3.w);
                 w2.load(twi_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
                 exchange<10, 3, 2, true>(re, im, myx, lane);
                 P12<R, G::LR - 1>::inv(re, im, w2.w);

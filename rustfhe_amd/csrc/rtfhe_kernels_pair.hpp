@@ -42,12 +42,12 @@
 #define PAIR_RAISE_AT 10     // round 3 (unpaired LDS exchanges, key switch out of the kernel): raising at the END of the step instead of
 #endif                       // before barrier 2 -- side 0's inverse then runs at low priority under side 1's R + inverse -- 6.81 -> 6.67 ms
                              // per 1024 gates (profiles/r03/pair_priority_grid.log)
-// A/B only (-DPAIR_TRIV=true -DPAIR_FIRST_ROW): the pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies
-// (fwd_stage_tw, TRIV0) and slot P's first row without its "+0.0 +".  64 fewer FP64 instructions per CMUX, same torus words --
-// and no faster (7.122 vs 7.122 ms per 1024 gates, profiles/r03/pair_lds_unpaired_reads_writes_ab.log): the kernel is not
-// bound by the FP64 instruction count alone.  Off by default: the shipped kernel executes the reference's operation list as is.
+// The pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies (fwd_stage_tw, TRIV0) and slot P's first row without its
+// "+0.0 +": 64 fewer FP64 instructions per CMUX, the same torus words.  History: with round 2's priority points this measured +-0 (7.122 vs
+// 7.122 ms per 1024 gates); with round 3's (raise at end of step) it is worth 3.5 % (7.22 -> 7.04 -> 6.97 ms on a slow box,
+// profiles/r03/pair_unit_twiddle_first_row_ab.log).  -DRTFHE_BOOT_TRIV=0 / -DPAIR_ZERO_FOLD: the reference's operation list as it stands.
 #ifndef PAIR_TRIV
-#define PAIR_TRIV false
+#define PAIR_TRIV BOOT_TRIV
 #endif
 
 namespace rtfhe {
@@ -295,11 +295,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 
         // slot P (side 0): component 0 over rows 0..2 from +0.0
         if (side == 0) {
-#ifdef PAIR_FIRST_ROW
-            mac_row_first<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
-#else
+#if defined(PAIR_ZERO_FOLD) || !RTFHE_BOOT_TRIV
             zero();
             mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
+#else
+            mac_row_first<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
 #endif
             mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, i, 3);
             mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, i, 4);

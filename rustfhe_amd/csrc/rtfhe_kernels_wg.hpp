@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             // second exchange buffer = this row's own (still unwritten) spectrum slot
             double* xim = reinterpret_cast<double*>(spec + (size_t)wave * P);
             if (wave < ROWS - 2) {
-                fft_forward<LOGN, true>(re, im, twf, xbuf, lane, xim);
+                fft_forward<LOGN, true, BOOT_TRIV>(re, im, twf, xbuf, lane, xim);
                 cplx* dst = spec + (size_t)wave * P + lane;
 #pragma unroll
                 for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             double re[R], im[R];
             double* xim = reinterpret_cast<double*>(spec + (size_t)frow * P);
-            fft_forward_tail<LOGN>(re, im, twf, xbuf, xim, lane);
+            fft_forward_tail<LOGN, BOOT_TRIV>(re, im, twf, xbuf, xim, lane);
             cplx* dst = spec + (size_t)frow * P + lane;
 #pragma unroll
             for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
 #pragma unroll
             for (int m = 0; m < R; m++) { const cplx v = src[m * 64]; re[m] = v.x; im[m] = v.y; }
             // the spectra are dead after the M phase: slot `wave` serves as the second exchange buffer
-            fft_inverse<LOGN, true>(re, im, twi, twi, xbuf, lane, reinterpret_cast<double*>(spec + (size_t)wave * P));
+            fft_inverse<LOGN, true, BOOT_TRIV>(re, im, twi, twi, xbuf, lane, reinterpret_cast<double*>(spec + (size_t)wave * P));
             uint32_t* poly = accbuf + wave * N;
 #pragma unroll
             for (int m = 0; m < R; m++) {

@@ -72,8 +72,10 @@ def test_dp_opcount_formula():
     import bench
     ops = bench.dp_wave_instr_per_cmux(1024, 3)
     assert ops["transform"] == 360 and ops["mac_row"] == 64
-    assert ops["total"] == 3808 and ops["add_mul"] == 3680 and ops["cvt_trunc"] == 128
+    assert ops["reference"] == 3808 and ops["cvt_trunc"] == 128
+    assert ops["total"] == 3808 - 8 * 6 - 16 and ops["add_mul"] == 3680 - 8 * 6 - 16      # unit-twiddle butterflies, first fold row
     assert bench.dp_wave_instr_per_cmux(2048, 3)["transform"] == 800
+    assert bench.dp_wave_instr_per_cmux(2048, 3)["reference"] == 8256 and bench.dp_wave_instr_per_cmux(2048, 3)["total"] == 8256 - 96
     assert abs(bench.FP64_VALU_PEAK - 39.3216e12) < 1e6
     assert bench.ALG_BYTES_PER_GATE == 78061008
 
@@ -98,8 +100,14 @@ def test_dp_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
     cvt = len(re.findall(r"^\s*v_(?:cvt_f64_i32|trunc_f64)", body, re.M))
     assert fused == 0, "-ffp-contract=off is what parity rests on"
     ops = bench.dp_wave_instr_per_cmux(1024, 3)
-    per_wave_arith, per_wave_cvt = ops["add_mul"] // 2, ops["cvt_trunc"] // 2
-    assert arith == per_wave_arith + 3 * ops["mac_row"], (arith, per_wave_arith)
+    per_wave_cvt = ops["cvt_trunc"] // 2
+    # static step-loop body of one wave's code: three forward transforms + one inverse (each without its unit-twiddle butterfly's 6), nine
+    # multiply-accumulate rows (slots P, Q, R) of which slot P's first lacks its 16 fold sums, the 16 magic-constant adds of the truncation
+    tr = ops["transform"] - ops["unit_twiddle_saved_per_transform"]
+    static = 4 * tr + 9 * ops["mac_row"] - ops["first_row_saved"] + 16
+    assert arith == static, (arith, static)
+    # ... and the per-gate count the roofline uses is what the two waves of a gate execute of it: P + Q on side 0, Q + R on side 1
+    assert ops["add_mul"] == 2 * (4 * tr + 6 * ops["mac_row"] + 16) - ops["first_row_saved"]
     assert cvt == per_wave_cvt, (cvt, per_wave_cvt)
 
 

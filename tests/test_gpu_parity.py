@@ -288,6 +288,22 @@ def test_twiddle_import_retransforms_a_torus_form_key(params, keys, gold_gate):
         e.set_twiddles(bad, fft)
         e.set_twiddles(ifft, fft)
         assert np.array_equal(e.gate_batch(R.NAND, in0, in1), want)
+        # The bootstrap kernels skip the multiplies of the butterfly whose twiddle is the first entry of the halfnn = 4 stage, which every
+        # table the reference builds holds as exactly (cos 0, sin 0) = (1, 0).  A table with anything else there is refused, and the refusal
+        # leaves the context as it was.  (Reference layout: per stage blocks of 4 cosines then 4 sines; the halfnn = 4 stage is the last
+        # 8 doubles written of the forward table and the first 8 of the inverse table.)
+        N = params.N
+        fwd_at = N + 2 * (N // 2 - 8)                           # twist (N doubles) + the stages halfnn = N/4 .. 8 (2 halfnn doubles each)
+        assert ifft[fwd_at] == 1.0 and ifft[fwd_at + 4] == 0.0 and fft[0] == 1.0 and fft[4] == 0.0
+        for table, at in ((ifft, fwd_at), (fft, 0)):
+            for off in (0, 4):
+                broken = table.copy()
+                broken[at + off] = np.nextafter(broken[at + off], 2.0)
+                with pytest.raises(R.RtfheError):
+                    e.set_twiddles(broken if table is ifft else ifft, broken if table is fft else fft)
+                a, b = e.twiddles()
+                assert a.tobytes() == ifft.tobytes() and b.tobytes() == fft.tobytes()
+        assert np.array_equal(e.gate_batch(R.NAND, in0, in1), want)
     finally:
         e.close()
 
