@@ -359,7 +359,7 @@ template <typename F>
 int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate) {
     a.mode = MODE_EXTRACT; a.ext = ctx->d_tlwe1;
     if (int rc = blind_rotate(ctx, a, s)) return rc;
-    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 63) / 64;
+    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 16 * KSMM_MT - 1) / (16 * KSMM_MT);
     // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
     int splitk = 1;
     while (splitk < 8 && (size_t)mgroups * colgroups * splitk < (size_t)8 * ctx->num_cus && (ctx->p.N / 4) % (8 * splitk) == 0) splitk *= 2;

@@ -132,9 +132,11 @@ __device__ __forceinline__ void fwd_stage_tw(double (&re)[R], double (&im)[R], c
 }
 
 // DIT, twiddled: t = x1 * w ; x0' = x0 + t ; x1' = x0 - t   (spqlios-fft-impl.cpp:346-359)
-// CONJ: w holds the FORWARD table's (c, s) and the stage multiplies by its conjugate (c, -s) -- what the reference's inverse
-// table contains (the host checks the two tables are exact conjugates before a kernel relies on it).  x * (-s) == -(x * s)
-// and a - (-b) == a + b exactly, so t0 + t3 / t2 - t1 are the bits the reference's t0 - t3' / t1' + t2 give.
+// CONJ (UNUSED by every shipped kernel, kept for the experiment recorded in DESIGN.md 5.4): w holds the FORWARD table's (c, s) and the
+// stage multiplies by its conjugate (c, -s).  x * (-s) == -(x * s) and a - (-b) == a + b exactly, so t0 + t3 / t2 - t1 are the bits
+// t0 - t3' / t1' + t2 give with (c, s') = (c, -s).  NOTE: the reference's inverse table is NOT the exact conjugate of its forward table (at
+// the quarter turn of every stage cos comes out as -6.1e-17 forward and +6.1e-17 inverse), and no host code checks for it: a kernel
+// that wanted CONJ = true would first have to patch those entries, as the N = 2048 experiment did.
 template <int R, int MB, bool CONJ = false, bool TRIV0 = false>
 __device__ __forceinline__ void inv_stage_tw(double (&re)[R], double (&im)[R], const cplx* w) {
     constexpr int h = 1 << MB;

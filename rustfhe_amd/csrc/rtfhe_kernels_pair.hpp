@@ -223,8 +223,19 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     // about evenly (measured: profiles/r01_pair/priority_schedule_ab.log).  Points: 0..5 after each half transform,
     // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
     auto prio_point = [&](int point) {   // one opaque statement each: no compiler-visible control flow inside the transforms
+#ifdef PAIR_MID_AT
+        if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
+#else
         if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
+#endif
         if (point == PAIR_RAISE_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
+#ifdef PAIR_MID_AT       // A/B: a third level for side 0 (priority 1 = side 1's) from PAIR_LOWER_AT to PAIR_MID_AT, 0 after it
+        if (point == PAIR_MID_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
+#endif
+#ifdef PAIR_S1_HIGH_AT   // A/B: side 1 at priority 3 from PAIR_S1_HIGH_AT to PAIR_S1_BACK_AT (its own points), 1 otherwise
+        if (point == PAIR_S1_HIGH_AT) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 3\n1:" ::"s"(side) : "scc");
+        if (point == PAIR_S1_BACK_AT) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
+#endif
     };
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
