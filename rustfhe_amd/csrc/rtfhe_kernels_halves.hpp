@@ -183,6 +183,63 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             // point by point: only one point's decomposition words and twiddles are live at a time.
             double yr[L][R], yi[L][R];
             const cplx* gtwist = gtwist0 + ln;
+#ifdef HALVES_SPLIT_STAGE1
+            // A/B only (round 3; the round-2 review's proposal, built and measured): each half gathers, decomposes and twists only ITS OWN inputs -- wave H owns x_H = point q + 512 H (coefficients q + 512 H and
+            // q + 512 (2 + H)) -- and the two waves trade the twisted values row by row through their exchange buffers (one row = 16 doubles per
+            // lane = one buffer pair): write, LDS barrier, read the partner's, LDS barrier (the partner has read mine).  Wave A then forms
+            // x0 + x1, wave B (x0 - x1) w -- the same operands in the same order as before, so the same bits -- at half the gathers, digit
+            // conversions and twist products per wave (round 2 computed both x0 and x1 in both waves: 384 of a wave's ~2,250 FP64-rate
+            // instructions per polynomial).  Six more barriers per polynomial; the next row's own products are computed between a row's read and
+            // the barrier that frees the buffer, so the partner's reads have them to land under.  All three rows at once would need 24 KiB per wave;
+            // a buffer pair holds 9.2 KiB and the workgroup's LDS is full.  MEASURED, identical outputs: 17.39 ms per 1024 gates against 17.08 ms
+            // with the duplicated first stage (300 gates: 13.21 vs 12.34 ms; profiles/r03/n2048_split_first_stage_ab.log) -- 17 % fewer FP64-rate
+            // instructions and SLOWER: at N = 2048 the two waves of a gate already meet at four barriers per step, twelve more cost more than
+            // the arithmetic they save.  Off by default.
+            uint32_t ure[R], uim[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const int c0 = ln + 64 * m + 512 * H, c1 = c0 + 1024;
+                ure[m] = ((rotated_coef<LOGN>(poly, c0, r) - poly[c0]) + M) ^ M;
+                uim[m] = ((rotated_coef<LOGN>(poly, c1, r) - poly[c1]) + M) ^ M;
+            }
+            cplx tH[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) tH[m] = gtwist[(8 * H + m) * 64];
+            double xr[R], xi[R];
+            auto own_row = [&](int jj) {
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const double a0 = (double)decomp_digit(ure[m], BGBIT, jj), b0 = (double)decomp_digit(uim[m], BGBIT, jj);
+                    const double rc = a0 * tH[m].x, ic = b0 * tH[m].x, rs = a0 * tH[m].y, is = b0 * tH[m].y;
+                    xr[m] = rc - is; xi[m] = ic + rs;
+                }
+            };
+            own_row(0);
+#pragma unroll
+            for (int jj = 0; jj < L; jj++) {
+#pragma unroll
+                for (int m = 0; m < R; m++) { lds_st(&myx[ln + 64 * m], xr[m]); lds_st(&myx[G::XSLOTS + ln + 64 * m], xi[m]); }
+                lds_barrier();
+                double pr[R], pi[R];
+#pragma unroll
+                for (int m = 0; m < R; m++) { pr[m] = lds_ld(&otx[ln + 64 * m]); pi[m] = lds_ld(&otx[G::XSLOTS + ln + 64 * m]); }
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    if (H == 0) {                       // mine = x0, partner's = x1
+                        yr[jj][m] = xr[m] + pr[m]; yi[jj][m] = xi[m] + pi[m];
+                    } else {                            // mine = x1, partner's = x0
+                        const cplx w1 = tw_st1[m * 64 + ln];
+                        const double dr = pr[m] - xr[m], di = pi[m] - xi[m];
+                        double p = dr * w1.x, q = di * w1.y;
+                        yr[jj][m] = p - q;
+                        p = dr * w1.y; q = di * w1.x;
+                        yi[jj][m] = p + q;
+                    }
+                }
+                if (jj + 1 < L) own_row(jj + 1);
+                lds_barrier();                          // both waves have read: the buffers are free (next row / the sub-transforms' exchanges)
+            }
+#else
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 uint32_t u[4];
@@ -214,6 +271,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 __builtin_amdgcn_sched_barrier(0);      // one point at a time: keeps the gather of later points from being hoisted
 #endif
             }
+#endif
             // the 512-point sub-transforms of the three rows side by side
             fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, myx, myx + G::XSLOTS, ln);
 #ifndef HALVES_FETCH_LATE
