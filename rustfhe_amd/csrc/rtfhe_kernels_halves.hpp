@@ -59,7 +59,8 @@ struct HalvesLds {
     static constexpr size_t TW = (size_t)HalvesTw::LDS_CPLX * sizeof(cplx);
     static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers: hold 512 cplx
     __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB; }
+    static constexpr size_t FLAGS = 16;       // two arrival counters per gate (pair_sync)
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB + FLAGS; }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
@@ -87,6 +88,11 @@ template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
 __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const HalvesArgs ha) {
     constexpr int LOGN = 11, N = 2048, P = 1024, R = 8, NT = 128 * GATES;
     typedef Geo<10> G;   // the 512-point sub-transform
+#ifdef HALVES_DUP_STAGE1      // A/B: both halves compute the whole first stage (round 2)
+    constexpr bool SPLIT1 = false;
+#else
+    constexpr bool SPLIT1 = GATES >= 3;      // each half twists only its own inputs and the halves trade them row by row (see below)
+#endif
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3, "three digit rows of a polynomial are transformed side by side");
     const BootstrapArgs& a = ha.b;
@@ -119,6 +125,17 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
     double* xb1 = xb0 + 2 * G::XSLOTS;
     double* myx = H ? xb1 : xb0;
     double* otx = H ? xb0 : xb1;
+    // arrival counters of the two halves of this gate (zeroed before the start-up barrier): the halves synchronise with each other only
+    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + HalvesLds::gate_bytes(a.npad) - HalvesLds::FLAGS);
+    if (lane0 == 0) flags[H] = 0u;
+    [[maybe_unused]] const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + H);
+    [[maybe_unused]] const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - H));
+    [[maybe_unused]] unsigned sync_k = 0;
+#ifdef HALVES_WG_BARRIER      // A/B: the workgroup-wide barrier of round 2
+#define HALVES_SYNC() lds_barrier()
+#else
+#define HALVES_SYNC() pair_sync(my_flag, partner_flag, ++sync_k)
+#endif
 
     const int n = a.n;
     {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
@@ -183,18 +200,19 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             // point by point: only one point's decomposition words and twiddles are live at a time.
             double yr[L][R], yi[L][R];
             const cplx* gtwist = gtwist0 + ln;
-#ifdef HALVES_SPLIT_STAGE1
-            // A/B only (round 3; the round-2 review's proposal, built and measured): each half gathers, decomposes and twists only ITS OWN inputs -- wave H owns x_H = point q + 512 H (coefficients q + 512 H and
+            if constexpr (SPLIT1) {
+            // Round 3 (the round-2 review's proposal): each half gathers, decomposes and twists only ITS OWN inputs -- wave H owns x_H = point q + 512 H (coefficients q + 512 H and
             // q + 512 (2 + H)) -- and the two waves trade the twisted values row by row through their exchange buffers (one row = 16 doubles per
             // lane = one buffer pair): write, LDS barrier, read the partner's, LDS barrier (the partner has read mine).  Wave A then forms
             // x0 + x1, wave B (x0 - x1) w -- the same operands in the same order as before, so the same bits -- at half the gathers, digit
             // conversions and twist products per wave (round 2 computed both x0 and x1 in both waves: 384 of a wave's ~2,250 FP64-rate
             // instructions per polynomial).  Six more barriers per polynomial; the next row's own products are computed between a row's read and
             // the barrier that frees the buffer, so the partner's reads have them to land under.  All three rows at once would need 24 KiB per wave;
-            // a buffer pair holds 9.2 KiB and the workgroup's LDS is full.  MEASURED, identical outputs: 17.39 ms per 1024 gates against 17.08 ms
-            // with the duplicated first stage (300 gates: 13.21 vs 12.34 ms; profiles/r03/n2048_split_first_stage_ab.log) -- 17 % fewer FP64-rate
-            // instructions and SLOWER: at N = 2048 the two waves of a gate already meet at four barriers per step, twelve more cost more than
-            // the arithmetic they save.  Off by default.
+            // a buffer pair holds 9.2 KiB and the workgroup's LDS is full, hence row by row.  MEASURED (profiles/r03/n2048_split_first_stage_ab.log,
+            // identical outputs): behind the workgroup-wide barrier the twelve extra synchronisations per step cost more than the 17 % of the
+            // arithmetic they save (17.39 vs 17.08 ms per 1024 gates); with the two halves of a gate synchronising with each other only (pair_sync:
+            // arrival counters in LDS) it wins where the SIMDs are full -- 4 gates per workgroup 16.87 vs 17.07 ms (60.7 k gates/s), 3 gates 16.26 vs
+            // 16.30 -- and loses where they are not (2 gates 13.04 vs 12.24, 1-2 gates 12.90 vs 12.13): on for GATES >= 3.
             uint32_t ure[R], uim[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             for (int jj = 0; jj < L; jj++) {
 #pragma unroll
                 for (int m = 0; m < R; m++) { lds_st(&myx[ln + 64 * m], xr[m]); lds_st(&myx[G::XSLOTS + ln + 64 * m], xi[m]); }
-                lds_barrier();
+                HALVES_SYNC();
                 double pr[R], pi[R];
 #pragma unroll
                 for (int m = 0; m < R; m++) { pr[m] = lds_ld(&otx[ln + 64 * m]); pi[m] = lds_ld(&otx[G::XSLOTS + ln + 64 * m]); }
@@ -237,9 +255,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                     }
                 }
                 if (jj + 1 < L) own_row(jj + 1);
-                lds_barrier();                          // both waves have read: the buffers are free (next row / the sub-transforms' exchanges)
+                HALVES_SYNC();                          // both waves have read: the buffers are free (next row / the sub-transforms' exchanges)
             }
-#else
+            } else {
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 uint32_t u[4];
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 }
 #ifndef HALVES_NO_POINT_BARRIER
                 __builtin_amdgcn_sched_barrier(0);      // one point at a time: keeps the gather of later points from being hoisted
-#endif
+            }
             }
 #endif
             // the 512-point sub-transforms of the three rows side by side
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             Tw<R> wt;      // untwist (times 2/N) of this half's points, from global memory: in flight across the barrier
 #pragma unroll
             for (int m = 0; m < R; m++) wt.w[m] = guntw0[(H * 8 + m) * 64 + lane];
-            lds_barrier();
+            HALVES_SYNC();
             {
                 uint32_t* poly = accbuf + comp * N;
 #pragma unroll
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                     poly[c + P] += trunc_to_torus(ic + rs);
                 }
             }
-            lds_barrier();     // the partner has read my buffer; both halves of the accumulator are written
+            HALVES_SYNC();     // the partner has read my buffer; both halves of the accumulator are written
         }
     }
     __builtin_amdgcn_s_setprio(0);
