@@ -64,7 +64,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // the first row of a fold: the reference adds it to FrrSeries::zero() (trgsw.rs:290-299); +0.0 + x == x for every x except that
 // it turns a -0.0 into +0.0, and the sign of a zero never reaches a torus word (see fwd_stage_tw in rtfhe_device.hpp)
-// A/B only (-DPAIR_FLAG_SYNC): synchronisation of the TWO waves of one gate only.  s_barrier is workgroup-wide although the four gates of a
+// Synchronisation of the TWO waves of one gate only (used at 2 / 3 gates per workgroup; -DPAIR_FLAG_SYNC / -DPAIR_WG_BARRIER force one form).  s_barrier is workgroup-wide although the four gates of a
 // workgroup share nothing after start-up; the phase stamps show BOTH sides of a pair ~1.1 k cycles "at barrier 1", which looked like the pairs
 // waiting for the slowest gate.  Here each side publishes an arrival counter in LDS after its hand-off stores and polls its partner's (DS
 // instructions of a wave execute in order, so a partner that sees counter >= k also sees the stores issued before it; no fence, which would wait
@@ -118,6 +118,17 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     constexpr int N = G::N, P = G::P, R = G::R, NT = 128 * GATES;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3, "three rows per side are held in registers");
+    // the two waves of a gate synchronise through the workgroup barrier when the workgroup is full (4 gates: 6.74 vs 6.76 ms with pair_sync) and
+    // with each other only when it is not (2 / 3 gates per workgroup: 4.34 vs 4.37 ms at 512 gates, 6.14 vs 6.20 at 768)
+#if defined(PAIR_FLAG_SYNC)
+    constexpr bool FLAG_A = true, FLAG_B = true;
+#elif defined(PAIR_WG_BARRIER)
+    constexpr bool FLAG_A = false, FLAG_B = false;
+#elif defined(PAIR_SYNC_MIXED)
+    constexpr bool FLAG_A = true, FLAG_B = false;
+#else
+    constexpr bool FLAG_A = GATES < 4, FLAG_B = GATES < 4;
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,15 +329,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
         prio_point(6);
         PAIR_STAMP(4);
-#ifdef PAIR_WG_BARRIER     // A/B: the workgroup-wide barrier of rounds 1-2
-#ifdef PAIR_FLAG_SYNC
-        pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u);
-#else
-        lds_barrier();
-#endif
-#else
-        pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u);
-#endif
+        if constexpr (FLAG_A) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u); else lds_barrier();
         prio_point(7);
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         put(side ? hand0 : hand1);
         prio_point(8);
         PAIR_STAMP(6);
-        lds_barrier();
+        if constexpr (FLAG_B) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();
         prio_point(9);
         PAIR_STAMP(7);
         // slot R (side 1): component 1 over rows 3..5 on top of side 0's partial sum; side 0 picks up the finished s0
