@@ -165,7 +165,8 @@ struct NttPairLds {
     static constexpr size_t TW = (size_t)ntt::TW_TOTAL * sizeof(double);
     static constexpr size_t XB = (size_t)ntt::XSLOTS * sizeof(double);
     static_assert(ntt::XSLOTS >= ntt::N, "an exchange buffer must hold one spectrum");
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * ntt::N * 4 + (size_t)npad * 4 + 2 * XB; }
+    static constexpr size_t FLAGS = 16;       // two arrival counters per gate (pair_sync, rtfhe_kernels_pair.hpp)
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * ntt::N * 4 + (size_t)npad * 4 + 2 * XB + FLAGS; }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
@@ -202,6 +203,18 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
     double* xb1 = xb0 + ntt::XSLOTS;
     double* myx = side ? xb1 : xb0;
     double* peerx = side ? xb0 : xb1;
+    // the two waves of a gate synchronise with each other only when the workgroup is not full (as in k_bootstrap_pair)
+    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + NttPairLds::gate_bytes(a.npad) - NttPairLds::FLAGS);
+    if (lane == 0) flags[side] = 0u;
+    [[maybe_unused]] const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side);
+    [[maybe_unused]] const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side));
+#if defined(NTT_PAIR_FLAG_SYNC)
+    constexpr bool FLAG_SYNC = true;
+#elif defined(NTT_PAIR_WG_BARRIER)
+    constexpr bool FLAG_SYNC = false;
+#else
+    constexpr bool FLAG_SYNC = GATES <= 2;      // measured: 512 gates 6.93 -> 6.69 ms; 768 gates 10.26 -> 10.49 (slower); 1024 gates equal
+#endif
     uint32_t* poly = accbuf + side * N;
     const int n = a.n;
     {
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
             for (int q = 0; q < R / 2; q++) ex[q * 64] = side ? make_double2(s0[2 * q], s0[2 * q + 1]) : make_double2(s1[2 * q], s1[2 * q + 1]);
         }
         prio_point(6);
-        lds_barrier();
+        if constexpr (FLAG_SYNC) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u); else lds_barrier();
         prio_point(7);
         double x[R];
         {
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
                 x[2 * q + 1] = (side ? s1[2 * q + 1] : s0[2 * q + 1]) + v.y;
             }
         }
-        lds_barrier();                    // both imports done: the exchange buffers are free for the inverse transforms
+        if constexpr (FLAG_SYNC) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();   // both imports done: the exchange buffers are free for the inverse transforms
         prio_point(8);
         ntt::inverse(x, twi, myx, lane);
 #pragma unroll
