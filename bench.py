@@ -572,11 +572,18 @@ def run_rank(args):
                 line["roofline"]["traffic_measured_in_this_run"] = False     # a builder-side rocprofv3 --pmc profile of the same device code
             else:
                 line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json is from other device code or another launch shape: not quoted"
+        # the headline above is complete at this point: a failure in one of the side measurements must not cost the line
         if n_gpus == 1 and not args.no_cpu_baseline and mirror and not config3:
-            line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
+            try:
+                line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
+            except Exception as e:          # noqa: BLE001
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if n_gpus == 1 and not args.no_secondary and mirror and not config3 and not args.gates:
             # the other BASELINE configs + the NTT backend on the same clock (headline fields above are not touched by this)
-            line["secondary"] = secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np)
+            try:
+                line["secondary"] = secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np)
+            except Exception as e:          # noqa: BLE001
+                line["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
