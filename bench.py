@@ -268,92 +268,114 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
     rng = np.random.default_rng(77)
 
     def timed(e, fn, reps):
-        fn(); e.sync(stream)
+        fn(); fn(); e.sync(stream)      # two untimed launches: the first ones after a change of kernel run at a lower clock
         e.timer_begin(stream)
         for _ in range(reps):
             fn()
         ms, ks_ms, n = e.timer_end_detail(stream)
         return ms / reps, ks_ms / reps
 
+    def guard(name, fn):             # one failing entry is recorded as such and does not cost the others
+        try:
+            fn()
+        except Exception as e:       # noqa: BLE001
+            sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                eng.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+            except Exception:        # noqa: BLE001
+                pass
+
     # -- BASELINE configs[0]: a single HomNAND gate (latency shape: one gate per 8-wave workgroup)
-    b = rng.integers(0, 2, (2, 8)).astype(np.uint8)
-    c0 = torch.from_numpy(R.encrypt_bits(params, key0, b[0], 11).view(np.int32)).to(gpu)
-    c1 = torch.from_numpy(R.encrypt_bits(params, key0, b[1], 12).view(np.int32)).to(gpu)
-    o = torch.empty_like(c0)
-    ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, c0, c1, o, 1, stream), 5)
-    sec["config1_single_gate"] = {"ms_per_gate": round(ms, 4), "kernel": "k_bootstrap_wg", "roofline_frac_fp64": fp64_frac(ops, params.n, 1, ms * 1e-3),
-                                  "note": "one gate on one CU: the fraction is of the WHOLE chip's ceiling (1/256 of it is reachable)"}
+    def _config1_single_gate():
+        b = rng.integers(0, 2, (2, 8)).astype(np.uint8)
+        c0 = torch.from_numpy(R.encrypt_bits(params, key0, b[0], 11).view(np.int32)).to(gpu)
+        c1 = torch.from_numpy(R.encrypt_bits(params, key0, b[1], 12).view(np.int32)).to(gpu)
+        o = torch.empty_like(c0)
+        ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, c0, c1, o, 1, stream), 5)
+        sec["config1_single_gate"] = {"ms_per_gate": round(ms, 4), "kernel": "k_bootstrap_wg", "roofline_frac_fp64": fp64_frac(ops, params.n, 1, ms * 1e-3),
+                                      "note": "one gate on one CU: the fraction is of the WHOLE chip's ceiling (1/256 of it is reachable)"}
+    guard("config1_single_gate", _config1_single_gate)
     # -- BASELINE configs[2] on one GPU: 8192 gates held on the device, scatter -> bootstrap -> gather inside the timed step
-    G3 = 8192
-    bb = rng.integers(0, 2, (2, G3)).astype(np.uint8)
-    f0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 21).view(np.int32)).to(gpu)
-    f1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 22).view(np.int32)).to(gpu)
-    sg = ShardedGates(engine_compute(eng, gpu), params.n + 1, gpu)
-    sg.run(R.NAND, f0, f1, G3)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.timer_begin(stream)
-    res = sg.run(R.NAND, f0, f1, G3, sync=torch.cuda.synchronize)
-    ms3, ks3, n3 = eng.timer_end_detail(stream)
-    torch.cuda.synchronize()
-    wall3 = time.perf_counter() - t0
-    ok3 = bool(np.array_equal(R.decrypt_bits(params, key0, res.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
-    sec["config3_8192_gates_one_gpu"] = {"gates_per_s": round(G3 / wall3, 1), "ms_per_step": round(wall3 * 1e3, 3),
-                                         "phase_ms": {k: round(1e3 * v, 3) for k, v in sg.last_timing.items()},
-                                         "kernel": "k_bootstrap_pair", "kernel_ms": round(ms3 - ks3, 3), "key_switch_kernel_ms": round(ks3, 3),
-                                         "roofline_frac_fp64": fp64_frac(ops, params.n, G3, (ms3 - ks3) * 1e-3), "ok": ok3}
-    del f0, f1, res
-    # -- BASELINE configs[3]: the 8-bit adder as a NAND netlist through the front-end, one replica, whole netlist = one HIP graph
-    adders = {}
-    for name, net in (("ripple_carry_nand_only", ripple_carry_adder(8, True)), ("ripple_carry_xor_and_or", ripple_carry_adder(8, False)),
-                      ("parallel_prefix_nand_only", prefix_adder(8, True)), ("parallel_prefix_xor_and_or", prefix_adder(8, False))):
-        A, B = int(rng.integers(0, 256)), int(rng.integers(0, 256))
-        bits = np.array([(A >> i) & 1 for i in range(8)] + [(B >> i) & 1 for i in range(8)], np.uint8)
-        run = CircuitRunner(eng, net, 1)
-        run.set_inputs(R.encrypt_bits(params, key0, bits, 31).reshape(1, 16, params.n + 1))
-        run.run()
+    def _config3_8192_gates_one_gpu():
+        G3 = 8192
+        bb = rng.integers(0, 2, (2, G3)).astype(np.uint8)
+        f0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 21).view(np.int32)).to(gpu)
+        f1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 22).view(np.int32)).to(gpu)
+        sg = ShardedGates(engine_compute(eng, gpu), params.n + 1, gpu)
+        sg.run(R.NAND, f0, f1, G3)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run.run()
+        eng.timer_begin(stream)
+        res = sg.run(R.NAND, f0, f1, G3, sync=torch.cuda.synchronize)
+        ms3, ks3, n3 = eng.timer_end_detail(stream)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        dec = R.decrypt_bits(params, key0, run.outputs().reshape(-1, params.n + 1))
-        d = net.describe()
-        adders[name] = {"ms_per_addition": round(dt * 1e3, 3), "gates": d["gates"], "levels": d["depth"], "kernel": "k_bootstrap_wg",
-                        "roofline_frac_fp64": fp64_frac(ops, params.n, d["gates"], dt), "ok": int((dec * (1 << np.arange(9))).sum()) == A + B}
-        run.close()
-    sec["config4_adder_8bit_one_replica"] = adders
+        wall3 = time.perf_counter() - t0
+        ok3 = bool(np.array_equal(R.decrypt_bits(params, key0, res.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+        sec["config3_8192_gates_one_gpu"] = {"gates_per_s": round(G3 / wall3, 1), "ms_per_step": round(wall3 * 1e3, 3),
+                                             "phase_ms": {k: round(1e3 * v, 3) for k, v in sg.last_timing.items()},
+                                             "kernel": "k_bootstrap_pair", "kernel_ms": round(ms3 - ks3, 3), "key_switch_kernel_ms": round(ks3, 3),
+                                             "roofline_frac_fp64": fp64_frac(ops, params.n, G3, (ms3 - ks3) * 1e-3), "ok": ok3}
+        del f0, f1, res
+    guard("config3_8192_gates_one_gpu", _config3_8192_gates_one_gpu)
+    # -- BASELINE configs[3]: the 8-bit adder as a NAND netlist through the front-end, one replica, whole netlist = one HIP graph
+    def _config4_adder_8bit_one_replica():
+        adders = {}
+        for name, net in (("ripple_carry_nand_only", ripple_carry_adder(8, True)), ("ripple_carry_xor_and_or", ripple_carry_adder(8, False)),
+                          ("parallel_prefix_nand_only", prefix_adder(8, True)), ("parallel_prefix_xor_and_or", prefix_adder(8, False))):
+            A, B = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+            bits = np.array([(A >> i) & 1 for i in range(8)] + [(B >> i) & 1 for i in range(8)], np.uint8)
+            run = CircuitRunner(eng, net, 1)
+            run.set_inputs(R.encrypt_bits(params, key0, bits, 31).reshape(1, 16, params.n + 1))
+            run.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run.run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            dec = R.decrypt_bits(params, key0, run.outputs().reshape(-1, params.n + 1))
+            d = net.describe()
+            adders[name] = {"ms_per_addition": round(dt * 1e3, 3), "gates": d["gates"], "levels": d["depth"], "kernel": "k_bootstrap_wg",
+                            "roofline_frac_fp64": fp64_frac(ops, params.n, d["gates"], dt), "ok": int((dec * (1 << np.arange(9))).sum()) == A + B}
+            run.close()
+        sec["config4_adder_8bit_one_replica"] = adders
+    guard("config4_adder_8bit_one_replica", _config4_adder_8bit_one_replica)
     # -- the NTT backend north_star names, 1024 gates (exact-integer arithmetic; decrypt-level parity with the reference)
-    G = 1024
-    bb = rng.integers(0, 2, (2, G)).astype(np.uint8)
-    d0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 41).view(np.int32)).to(gpu)
-    d1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 42).view(np.int32)).to(gpu)
-    do = torch.empty_like(d0)
-    eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
-    ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, d0, d1, do, G, stream), 3)
-    okn = bool(np.array_equal(R.decrypt_bits(params, key0, do.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
-    eng.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
-    nops = ntt_dp_wave_instr_per_cmux(params.N, params.l)["total"]
-    sec["ntt_exact_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_ntt_pair",
-                                   "roofline_frac_fp64": fp64_frac(nops, params.n, G, ms * 1e-3), "ok": okn}
+    def _ntt_exact_1024_gates():
+        G = 1024
+        bb = rng.integers(0, 2, (2, G)).astype(np.uint8)
+        d0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 41).view(np.int32)).to(gpu)
+        d1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 42).view(np.int32)).to(gpu)
+        do = torch.empty_like(d0)
+        eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, d0, d1, do, G, stream), 5)
+        okn = bool(np.array_equal(R.decrypt_bits(params, key0, do.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+        eng.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+        nops = ntt_dp_wave_instr_per_cmux(params.N, params.l)["total"]
+        sec["ntt_exact_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_ntt_pair",
+                                       "roofline_frac_fp64": fp64_frac(nops, params.n, G, ms * 1e-3), "ok": okn}
+    guard("ntt_exact_1024_gates", _ntt_exact_1024_gates)
     # -- BASELINE configs[4]: N = 2048, 1024 gates (its own key set and context)
-    p5 = R.Params(N=2048)
-    k0, k1, bk5, ksk5 = R.keygen(p5, 20482048)
-    e5 = R.Engine(p5, gpu.index)
-    try:
-        e5.load_bk_torus(bk5)
-        e5.load_ksk(ksk5)
-        del bk5, ksk5
-        x0 = torch.from_numpy(R.encrypt_bits(p5, k0, bb[0], 51).view(np.int32)).to(gpu)
-        x1 = torch.from_numpy(R.encrypt_bits(p5, k0, bb[1], 52).view(np.int32)).to(gpu)
-        xo = torch.empty_like(x0)
-        ms, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xo, G, stream), 3)
-        ok5 = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
-        ops5 = dp_wave_instr_per_cmux(2048, p5.l)["total"]
-        sec["config5_n2048_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_halves",
-                                           "dp_wave_instr_per_cmux": ops5, "roofline_frac_fp64": fp64_frac(ops5, p5.n, G, ms * 1e-3), "ok": ok5}
-    finally:
-        e5.close()
+    def _config5_n2048_1024_gates():
+        G = 1024
+        bb = rng.integers(0, 2, (2, G)).astype(np.uint8)
+        p5 = R.Params(N=2048)
+        k0, k1, bk5, ksk5 = R.keygen(p5, 20482048)
+        e5 = R.Engine(p5, gpu.index)
+        try:
+            e5.load_bk_torus(bk5)
+            e5.load_ksk(ksk5)
+            del bk5, ksk5
+            x0 = torch.from_numpy(R.encrypt_bits(p5, k0, bb[0], 51).view(np.int32)).to(gpu)
+            x1 = torch.from_numpy(R.encrypt_bits(p5, k0, bb[1], 52).view(np.int32)).to(gpu)
+            xo = torch.empty_like(x0)
+            ms, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xo, G, stream), 5)
+            ok5 = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+            ops5 = dp_wave_instr_per_cmux(2048, p5.l)["total"]
+            sec["config5_n2048_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_halves",
+                                               "dp_wave_instr_per_cmux": ops5, "roofline_frac_fp64": fp64_frac(ops5, p5.n, G, ms * 1e-3), "ok": ok5}
+        finally:
+            e5.close()
+    guard("config5_n2048_1024_gates", _config5_n2048_1024_gates)
     return sec
 
 
