@@ -224,8 +224,11 @@ struct rtfhe_ctx {
     uint32_t* d_ksk = nullptr;
     int ksw = 0;
     uint4* d_ksmat = nullptr;         // the key-switching key as signed byte limbs in i8-MFMA operand order (rtfhe_kernels_ksmm.hpp)
-    uint32_t* d_tlwe1 = nullptr;      // lvl1 samples between the two launches of the split path
-    size_t cap_tlwe1 = 0;             // in gates
+    // lvl1 samples between the two launches of the split path: ONE buffer per stream a batch was ever launched on (launches of one stream are
+    // ordered, launches on different streams of one context may overlap and must not share it), plus a circuit's own during its capture
+    struct Tlwe1 { uint32_t* d = nullptr; size_t cap = 0; };     // cap in gates
+    std::unordered_map<hipStream_t, Tlwe1> tlwe1;
+    Tlwe1* tlwe1_capture = nullptr;   // set by rtfhe_circuit_create around its capture: the circuit's buffer
     int ks_mm_min = 1;                // batches of at least this many gates take the split path (0 = never: fused kernel); RTFHE_KS_MM_MIN
     bool has_bk = false, has_ksk = false;
     void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr;   // device staging for host-pointer calls
@@ -263,6 +266,7 @@ struct rtfhe_circuit {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int device = 0;            // kept here: the context may be destroyed before the circuit
+    uint32_t* d_samples = nullptr;   // the circuit's own lvl1 sample buffer (split path): replays on any stream never share one with other work
     int32_t waves = 0;
     int64_t launches = 0;      // kernel launches one replay stands for
 };
@@ -272,7 +276,8 @@ static void circuit_release(rtfhe_circuit* c) {
     (void)hipSetDevice(c->device);
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->exec = nullptr; c->graph = nullptr;
+    if (c->d_samples) (void)hipFree(c->d_samples);
+    c->exec = nullptr; c->graph = nullptr; c->d_samples = nullptr;
 }
 
 namespace {
@@ -338,26 +343,33 @@ int allow_lds(rtfhe_ctx* ctx, K kernel, size_t bytes) {
 // (the bootstrap kernel in MODE_EXTRACT, launched by `blind_rotate`), then the key switch of the whole batch as one exact i8
 // contraction on the matrix pipe (k_key_switch_mm) -- two launches back to back on the caller's stream, the lvl1 samples in between
 // stay in HBM (4 MB per 1024 gates at N = 1024).
-bool split_ok(const rtfhe_ctx* ctx, const BootstrapArgs& a) {
-    return a.mode == MODE_GATE && ctx->d_ksmat && ctx->ks_mm_min > 0 && (size_t)a.count >= (size_t)ctx->ks_mm_min &&
-           (size_t)a.count <= ctx->cap_tlwe1;      // (the sample buffer is sized by ensure_tlwe1 before any launch or capture)
+rtfhe_ctx::Tlwe1* tlwe1_of(rtfhe_ctx* ctx, hipStream_t s) {
+    if (ctx->tlwe1_capture) return ctx->tlwe1_capture;
+    auto it = ctx->tlwe1.find(s);
+    return it == ctx->tlwe1.end() ? nullptr : &it->second;
 }
-// lvl1 sample buffer of the split path: sized outside launches (hipMalloc is not allowed inside a stream capture)
-int ensure_tlwe1(rtfhe_ctx* ctx, size_t gates) {
-    if (ctx->cap_tlwe1 >= gates) return 0;
+bool split_ok(rtfhe_ctx* ctx, const BootstrapArgs& a, hipStream_t s) {
+    if (!(a.mode == MODE_GATE && ctx->d_ksmat && ctx->ks_mm_min > 0 && (size_t)a.count >= (size_t)ctx->ks_mm_min)) return false;
+    const rtfhe_ctx::Tlwe1* b = tlwe1_of(ctx, s);
+    return b && (size_t)a.count <= b->cap;      // (the sample buffer is sized by ensure_tlwe1 before any launch or capture)
+}
+// lvl1 sample buffer of the split path for stream s: sized outside launches (hipMalloc is not allowed inside a stream capture)
+int ensure_tlwe1(rtfhe_ctx* ctx, rtfhe_ctx::Tlwe1& b, size_t gates) {
+    if (b.cap >= gates) return 0;
     HIPCHECK(ctx, hipDeviceSynchronize());            // earlier launches may still read the old buffer
-    if (ctx->d_tlwe1) HIPCHECK(ctx, hipFree(ctx->d_tlwe1));
-    ctx->d_tlwe1 = nullptr; ctx->cap_tlwe1 = 0;
-    const size_t cap = gates < 8192 ? 8192 : gates;
-    HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tlwe1, cap * ((size_t)ctx->p.N + 1) * 4));
-    ctx->cap_tlwe1 = cap;
+    if (b.d) HIPCHECK(ctx, hipFree(b.d));
+    b.d = nullptr; b.cap = 0;
+    const size_t cap = gates < 1024 ? 1024 : gates;
+    HIPCHECK(ctx, hipMalloc((void**)&b.d, cap * ((size_t)ctx->p.N + 1) * 4));
+    b.cap = cap;
     return 0;
 }
 // blind_rotate(ctx, a', s) launches the bootstrap kernel(s) of the whole batch with a'.mode = MODE_EXTRACT: every gate's lvl1 sample goes to
 // a'.ext (segments of a batch advance it by N + 1 words per gate) and its output row is zeroed for the key switch's atomics
 template <typename F>
 int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate) {
-    a.mode = MODE_EXTRACT; a.ext = ctx->d_tlwe1;
+    uint32_t* samples = tlwe1_of(ctx, s)->d;
+    a.mode = MODE_EXTRACT; a.ext = samples;
     if (int rc = blind_rotate(ctx, a, s)) return rc;
     const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 16 * KSMM_MT - 1) / (16 * KSMM_MT);
     // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
@@ -370,7 +382,7 @@ int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate)
         ctx->ks_events_used += 2;
         HIPCHECK(ctx, hipEventRecord(ev_a, s));
     }
-    KsMmArgs k{ctx->d_tlwe1, ctx->d_ksmat, a.out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk, a.ops, a.idx0, a.idx1, a.idx_out, a.num_wires};
+    KsMmArgs k{samples, ctx->d_ksmat, a.out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk, a.ops, a.idx0, a.idx1, a.idx_out, a.num_wires};
     hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
     HIPCHECK(ctx, hipGetLastError());
     if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
@@ -456,7 +468,7 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         if (force == 2) return launch_bootstrap_pair10(ctx, a, s);
         if (force == 8) return launch_bootstrap_w<10, 8>(ctx, a, s);
         if (force == 4) return launch_bootstrap_w<10, 4>(ctx, a, s);
-        if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_t<10>);     // comes back here in MODE_EXTRACT
+        if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_bootstrap_t<10>);     // comes back here in MODE_EXTRACT
         const size_t out_words = mode_out_words(a, 1 << LOGN);
         const size_t round = (size_t)4 * ctx->num_cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
@@ -476,7 +488,7 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         if (!(ctx->d_htw && ctx->d_hbk) || ctx->force_waves == 4) return launch_bootstrap_w<11, 4>(ctx, a, s);
         // whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU
         // (a gate's two waves then share their SIMDs with fewer other waves: a single gate takes 0.67 x a full round)
-        if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_t<11>);
+        if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_bootstrap_t<11>);
         const size_t out_words = mode_out_words(a, 1 << LOGN);
         const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
@@ -629,7 +641,7 @@ int launch_bootstrap_ntt_wg(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
 // workgroup (one workgroup per CU): with fewer gates per CU a gate's two waves share their SIMDs with fewer other waves -- a
 // circuit wave of 1-3 gates takes 0.67 x the time of a full round instead of all of it.
 int launch_bootstrap_ntt_pair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_ntt_pair);
+    if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_bootstrap_ntt_pair);
     const size_t out_words = mode_out_words(a, ntt::N);
     const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
@@ -660,7 +672,7 @@ int launch_bootstrap_ntt_halves_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s
 #define NTT_HALVES_ROUND 4
 #endif
 int launch_bootstrap_ntt_halves(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
-    if (split_ok(ctx, a)) return launch_split(ctx, a, s, launch_bootstrap_ntt_halves);
+    if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_bootstrap_ntt_halves);
     const size_t out_words = mode_out_words(a, 2048);
     const size_t cus = (size_t)ctx->num_cus, round = NTT_HALVES_ROUND * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
@@ -690,12 +702,16 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.num_wires = num_wires; a.fault = ctx->d_fault;
     a.dbg = ctx->d_dbg;
     a.ext = nullptr;
-    if (mode == MODE_GATE && ctx->ks_mm_min > 0 && ctx->d_ksmat && count > ctx->cap_tlwe1) {
-        // the split path's sample buffer grows here, outside any stream capture (inside one the batch stays on the fused kernel)
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
-        if (cs == hipStreamCaptureStatusNone)
-            if (int rc = ensure_tlwe1(ctx, count)) return rc;
+    if (mode == MODE_GATE && ctx->ks_mm_min > 0 && ctx->d_ksmat && !ctx->tlwe1_capture) {
+        // the split path's sample buffer of this stream is created / grows here, outside any stream capture (inside a capture that
+        // is not rtfhe_circuit_create's own, a batch that finds no large enough buffer stays on the fused kernel)
+        const rtfhe_ctx::Tlwe1* have = tlwe1_of(ctx, s);
+        if (!have || count > have->cap) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+            if (cs == hipStreamCaptureStatusNone)
+                if (int rc = ensure_tlwe1(ctx, ctx->tlwe1[s], count)) return rc;
+        }
     }
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
         if (int rc = ntt_prepare(ctx)) return rc;
@@ -1078,7 +1094,7 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);
     if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
     if (ctx->d_ksmat) (void)hipFree(ctx->d_ksmat);
-    if (ctx->d_tlwe1) (void)hipFree(ctx->d_tlwe1);
+    for (auto& kv : ctx->tlwe1) if (kv.second.d) (void)hipFree(kv.second.d);
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_b) (void)hipFree(ctx->d_b);
     if (ctx->d_c) (void)hipFree(ctx->d_c);
@@ -1212,7 +1228,7 @@ int rtfhe_load_ksk(rtfhe_ctx* ctx, const uint32_t* ksk) {
         hipLaunchKernelGGL((k_ksmat_build<8, 2>), dim3(4096), dim3(256), 0, ctx->stream, m);
         HIPCHECK(ctx, hipGetLastError());
         HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (int rc = ensure_tlwe1(ctx, 8192)) return rc;
+        if (int rc = ensure_tlwe1(ctx, ctx->tlwe1[ctx->stream], 8192)) return rc;     // the context's own stream (host-pointer calls)
     }
     ctx->has_ksk = true;
     for (rtfhe_ctx* peer : ctx->peers) {
@@ -1275,32 +1291,35 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
         return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_create needs device pointers (got memory the GPU cannot address)");
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT)
         if (int rc = ntt_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
-    if (ctx->ks_mm_min > 0 && ctx->d_ksmat) {              // ... so the split path's sample buffer is sized for the largest wave now
+    rtfhe_ctx::Tlwe1 cbuf;                                 // ... so the circuit's own sample buffer (split path) is allocated now
+    if (ctx->ks_mm_min > 0 && ctx->d_ksmat) {
         size_t widest = 0;
         for (int32_t w = 0; w < num_waves; w++) widest = std::max(widest, (size_t)(wave_offsets[w + 1] - wave_offsets[w]));
-        if (int rc = ensure_tlwe1(ctx, widest)) return rc;
+        if (int rc = ensure_tlwe1(ctx, cbuf, widest)) return rc;
     }
     rtfhe_circuit* c = new (std::nothrow) rtfhe_circuit();
-    if (!c) return fail(ctx, RTFHE_ERR_NOMEM, "out of host memory");
-    c->ctx = ctx; c->device = ctx->device; c->waves = num_waves;
+    if (!c) { if (cbuf.d) (void)hipFree(cbuf.d); return fail(ctx, RTFHE_ERR_NOMEM, "out of host memory"); }
+    c->ctx = ctx; c->device = ctx->device; c->waves = num_waves; c->d_samples = cbuf.d;
     const int64_t before = ctx->launches;
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { circuit_release(c); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
     int rc = 0;
+    ctx->tlwe1_capture = cbuf.d ? &cbuf : nullptr;
     for (int32_t w = 0; w < num_waves && !rc; w++) {
         const size_t off = (size_t)wave_offsets[w], cnt = (size_t)(wave_offsets[w + 1] - wave_offsets[w]);
         rc = launch_bootstrap(ctx, RTFHE_COPY, MODE_GATE, ctx->p.n, d_wires, d_wires, d_wires, cnt, ctx->stream,
                               (const int32_t*)d_ops + off, (const int32_t*)d_idx0 + off, (const int32_t*)d_idx1 + off,
                               (const int32_t*)d_idx_out + off, (int32_t)num_wires);
     }
+    ctx->tlwe1_capture = nullptr;
     e = hipStreamEndCapture(ctx->stream, &c->graph);
     c->launches = ctx->launches - before;
     ctx->launches = before;
-    if (rc) { if (c->graph) (void)hipGraphDestroy(c->graph); delete c; return rc; }
-    if (e != hipSuccess) { delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+    if (rc) { circuit_release(c); delete c; return rc; }
+    if (e != hipSuccess) { circuit_release(c); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
     e = hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGraphDestroy(c->graph); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { circuit_release(c); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     ctx->circuits.push_back(c);
     *out = c;
     return 0;

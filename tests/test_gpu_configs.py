@@ -445,3 +445,26 @@ def test_batch_key_switch_split_path_n2048(monkeypatch):
         assert list(R.decrypt_bits(p, key0, split.gate_batch(R.NAND, e0, e1))) == list(1 - (bits[0] & bits[1]))
     finally:
         fused.close(); split.close()
+
+
+def test_batches_on_two_streams_of_one_context_do_not_share_scratch(engine, keys):
+    """The split path keeps the lvl1 samples of a batch in a scratch buffer between its two launches: one buffer PER STREAM, so that
+    batches enqueued on different streams of one context (which may overlap on the device) cannot overwrite each other's samples."""
+    import torch
+    import rustfhe_amd as R
+    rng = np.random.default_rng(99)
+    G = 700
+    bits = rng.integers(0, 2, (4, G))
+    c = [torch.from_numpy(keys.encrypt_bits(b).view(np.int32)).cuda() for b in bits]
+    ref0 = engine.gate_batch(R.NAND, c[0].cpu().numpy().view(np.uint32), c[1].cpu().numpy().view(np.uint32))
+    ref1 = engine.gate_batch(R.XOR, c[2].cpu().numpy().view(np.uint32), c[3].cpu().numpy().view(np.uint32))
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    o0, o1 = torch.empty_like(c[0]), torch.empty_like(c[0])
+    torch.cuda.synchronize()
+    for _ in range(3):                              # several rounds: the two streams' launches interleave differently each time
+        engine.gate_batch_dev(R.NAND, c[0], c[1], o0, G, s0.cuda_stream)
+        engine.gate_batch_dev(R.XOR, c[2], c[3], o1, G, s1.cuda_stream)
+        engine.gate_batch_dev(R.NAND, c[0], c[1], o0, G, s0.cuda_stream)
+        engine.sync(s0.cuda_stream); engine.sync(s1.cuda_stream)
+        assert np.array_equal(o0.cpu().numpy().view(np.uint32), ref0)
+        assert np.array_equal(o1.cpu().numpy().view(np.uint32), ref1)
