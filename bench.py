@@ -97,11 +97,12 @@ def ntt_dp_wave_instr_per_cmux(N=1024, l=3):
 
 
 def kernel_src_hash():
-    """Identifies the device code a PMC profile was taken with (profiles/pmc_traffic.json is refused when it differs)."""
+    """Identifies the device code a PMC profile was taken with (profiles/pmc_traffic.json is refused when it differs): every kernel lives
+    in a header under rustfhe_amd/csrc/ (*.hpp); the .hip / .cpp files there are host code (C ABI, key generation, files)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rustfhe_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hpp", ".hip", ".h")):
+        if f.endswith(".hpp"):
             h.update(f.encode())
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(fh.read())
