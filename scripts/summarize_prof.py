@@ -21,6 +21,10 @@ for f in glob.glob(os.path.join(out_dir, "kt", "**", "*kernel_stats.csv"), recur
     for r in rows:
         summary["kernels"][r["Name"][:120]] = {k: r[k] for k in r if k != "Name"}
 
+for f in glob.glob(os.path.join(out_dir, "kt_all", "**", "*kernel_stats.csv"), recursive=True):      # bench.py with its secondary measurements
+    with open(os.path.join(dst, "kernel_stats_all_configs.csv"), "w") as o:
+        o.write(open(f).read())
+
 for f in glob.glob(os.path.join(out_dir, "kt", "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
