@@ -34,6 +34,10 @@
 #define HALVES_PRIO_B 1      // wave B carries ~9 % more arithmetic (the first-stage / last-stage twiddle products)
 #endif
 
+#ifndef HALVES_SPLIT_MIN
+#define HALVES_SPLIT_MIN 3   // gates per workgroup from which the two halves trade the first stage's inputs instead of both computing all of them
+#endif
+
 namespace rtfhe {
 
 // twiddle table of the halves kernel, cplx units: forward part, then inverse part
@@ -91,7 +95,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #ifdef HALVES_DUP_STAGE1      // A/B: both halves compute the whole first stage (round 2)
     constexpr bool SPLIT1 = false;
 #else
-    constexpr bool SPLIT1 = GATES >= 3;      // each half twists only its own inputs and the halves trade them row by row (see below)
+    constexpr bool SPLIT1 = GATES >= HALVES_SPLIT_MIN;      // each half twists only its own inputs and the halves trade them row by row (see below)
+#endif
+    // half 1's last-stage twiddles of the inverse (global memory) requested one pass ahead of their use: 11.86 -> 11.72 ms per 512 gates; with the split
+    // first stage the same request costs 36 spilled registers (17.6 vs 16.65 ms per 1024 gates), so only without it
+#ifdef HALVES_IST_LATE
+    constexpr bool IST_EARLY = false;
+#else
+    constexpr bool IST_EARLY = !SPLIT1;
 #endif
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3, "three digit rows of a polynomial are transformed side by side");
@@ -108,10 +119,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
     const cplx* twi_small = tw + HalvesTw::LDS_FWD - G::TW_P2;            // twi_small + G::TW_P2/P3: the inverse's pass-2/3 tables
     static_assert(HalvesTw::P2 - HalvesTw::P1 == G::TW_P2 - G::TW_P1 && HalvesTw::P3 - HalvesTw::P2 == G::TW_P3 - G::TW_P2 &&
                   HalvesTw::IP3 - HalvesTw::IP2 == G::TW_P3 - G::TW_P2, "same table geometry as Geo<10>");
+#ifdef HALVES_ABL_LDSTW         // timing ablation only (wrong results): the tables that live in global memory are read from LDS addresses instead
+    const cplx* gtwist0 = tw; const cplx* guntw0 = tw; const cplx* gist10 = tw; const cplx* gip10 = tw;
+#else
     const cplx* gtwist0 = ha.htw + HalvesTw::TWIST;           // [16][64] in global memory
     const cplx* guntw0 = ha.htw + HalvesTw::IUNTW;            // [16][64]
     const cplx* gist10 = ha.htw + HalvesTw::IST1;             // [8][64]
     const cplx* gip10 = ha.htw + HalvesTw::IP1;               // [7][64]
+#endif
 
     const int g_raw = blockIdx.x * GATES + slot;
     const int g = g_raw < a.count ? g_raw : a.count - 1;
@@ -135,6 +150,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #define HALVES_SYNC() lds_barrier()
 #else
 #define HALVES_SYNC() pair_sync(my_flag, partner_flag, ++sync_k)
+#endif
+#ifdef HALVES_ABL_NOSYNC       // timing ablation only (racy, wrong results)
+#undef HALVES_SYNC
+#define HALVES_SYNC() wave_lds_sync()
 #endif
 
     const int n = a.n;
@@ -164,6 +183,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
     const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(ha.hbk), 0, 0x7fffffff, 0x00020000);
     const int lane16 = lane0 * 16;
     auto fetch = [&](cplx (&dst)[R], int step, int rc) {
+#ifdef HALVES_ABL_FETCH0       // timing ablation only (wrong results): every step reads step 0's key rows (cache-hot)
+        step = 0;
+#endif
         const size_t row = (size_t)step * trgsw_cplx + (size_t)((rc >> 1) * 2 + (rc & 1)) * 2 * R * 64 + (size_t)H * R * 64;
         const int s_lo = __builtin_amdgcn_readfirstlane((int)(row * sizeof(cplx)));
         const int s_hi = s_lo + (R / 2) * 64 * (int)sizeof(cplx);
@@ -213,6 +235,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             // arithmetic they save (17.39 vs 17.08 ms per 1024 gates); with the two halves of a gate synchronising with each other only (pair_sync:
             // arrival counters in LDS) it wins where the SIMDs are full -- 4 gates per workgroup 16.87 vs 17.07 ms (60.7 k gates/s), 3 gates 16.26 vs
             // 16.30 -- and loses where they are not (2 gates 13.04 vs 12.24, 1-2 gates 12.90 vs 12.13): on for GATES >= 3.
+            cplx tH[R];        // twist factors of this half's points, from global memory: requested before the gather they land under
+#pragma unroll
+            for (int m = 0; m < R; m++) tH[m] = gtwist[(8 * H + m) * 64];
             uint32_t ure[R], uim[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
@@ -220,9 +245,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 ure[m] = ((rotated_coef<LOGN>(poly, c0, r) - poly[c0]) + M) ^ M;
                 uim[m] = ((rotated_coef<LOGN>(poly, c1, r) - poly[c1]) + M) ^ M;
             }
-            cplx tH[R];
-#pragma unroll
-            for (int m = 0; m < R; m++) tH[m] = gtwist[(8 * H + m) * 64];
             double xr[R], xi[R];
             auto own_row = [&](int jj) {
 #pragma unroll
@@ -238,16 +260,19 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #pragma unroll
                 for (int m = 0; m < R; m++) { lds_st(&myx[ln + 64 * m], xr[m]); lds_st(&myx[G::XSLOTS + ln + 64 * m], xi[m]); }
                 HALVES_SYNC();
-                double pr[R], pi[R];
+                // the branch on the (wave-uniform) half stays OUTSIDE the point loop: inside it the compiler emits one branch and one LDS wait per
+                // point (48 per step) and nothing is scheduled across them
+                if (H == 0) {                           // mine = x0, partner's = x1
 #pragma unroll
-                for (int m = 0; m < R; m++) { pr[m] = lds_ld(&otx[ln + 64 * m]); pi[m] = lds_ld(&otx[G::XSLOTS + ln + 64 * m]); }
+                    for (int m = 0; m < R; m++) {
+                        yr[jj][m] = xr[m] + lds_ld(&otx[ln + 64 * m]);
+                        yi[jj][m] = xi[m] + lds_ld(&otx[G::XSLOTS + ln + 64 * m]);
+                    }
+                } else {                                // mine = x1, partner's = x0
 #pragma unroll
-                for (int m = 0; m < R; m++) {
-                    if (H == 0) {                       // mine = x0, partner's = x1
-                        yr[jj][m] = xr[m] + pr[m]; yi[jj][m] = xi[m] + pi[m];
-                    } else {                            // mine = x1, partner's = x0
+                    for (int m = 0; m < R; m++) {
                         const cplx w1 = tw_st1[m * 64 + ln];
-                        const double dr = pr[m] - xr[m], di = pi[m] - xi[m];
+                        const double dr = lds_ld(&otx[ln + 64 * m]) - xr[m], di = lds_ld(&otx[G::XSLOTS + ln + 64 * m]) - xi[m];
                         double p = dr * w1.x, q = di * w1.y;
                         yr[jj][m] = p - q;
                         p = dr * w1.y; q = di * w1.x;
@@ -267,18 +292,23 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                     u[k] = ((rotated_coef<LOGN>(poly, c, r) - poly[c]) + M) ^ M;
                 }
                 const cplx t0 = gtwist[m * 64], t1 = gtwist[(8 + m) * 64], w1 = tw_st1[m * 64 + ln];
+                double x0r[L], x0i[L], x1r[L], x1i[L];
 #pragma unroll
                 for (int jj = 0; jj < L; jj++) {
                     const double a0 = (double)decomp_digit(u[0], BGBIT, jj), b0 = (double)decomp_digit(u[2], BGBIT, jj);
                     const double a1 = (double)decomp_digit(u[1], BGBIT, jj), b1 = (double)decomp_digit(u[3], BGBIT, jj);
                     const double rc0 = a0 * t0.x, ic0 = b0 * t0.x, rs0 = a0 * t0.y, is0 = b0 * t0.y;
-                    const double x0r = rc0 - is0, x0i = ic0 + rs0;
+                    x0r[jj] = rc0 - is0; x0i[jj] = ic0 + rs0;
                     const double rc1 = a1 * t1.x, ic1 = b1 * t1.x, rs1 = a1 * t1.y, is1 = b1 * t1.y;
-                    const double x1r = rc1 - is1, x1i = ic1 + rs1;
-                    if (H == 0) {
-                        yr[jj][m] = x0r + x1r; yi[jj][m] = x0i + x1i;
-                    } else {
-                        const double dr = x0r - x1r, di = x0i - x1i;
+                    x1r[jj] = rc1 - is1; x1i[jj] = ic1 + rs1;
+                }
+                if (H == 0) {                           // one branch per point, not one per point and row
+#pragma unroll
+                    for (int jj = 0; jj < L; jj++) { yr[jj][m] = x0r[jj] + x1r[jj]; yi[jj][m] = x0i[jj] + x1i[jj]; }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < L; jj++) {
+                        const double dr = x0r[jj] - x1r[jj], di = x0i[jj] - x1i[jj];
                         double p = dr * w1.x, q = di * w1.y;
                         yr[jj][m] = p - q;
                         p = dr * w1.y; q = di * w1.x;
@@ -320,6 +350,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             for (int m = 0; m < R; m++) { re[m] = comp ? s1re[m] : s0re[m]; im[m] = comp ? s1im[m] : s0im[m]; }
             int lane = lane0;
             asm volatile("" : "+v"(lane));      // as above: addresses are re-derived here instead of living (spilled) across the step
+            [[maybe_unused]] cplx wl[R];        // half 1: last-stage twiddles (global memory), requested with the pass-1 table
             {
                 Tw<G::NLOW - 4> w3; Tw<R - 1> w2, w1;
                 w1.load(gip10 + lane, 64);                  // global memory: requested first, used last
@@ -329,6 +360,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 exchange<10, 3, 2, true>(re, im, myx, lane);
                 P12<R, G::LR - 1>::inv(re, im, w2.w);
                 exchange<10, 2, 1, true>(re, im, myx, lane);
+                if constexpr (IST_EARLY) {
+                    if (H == 1) {   // requested under the last pass
+#pragma unroll
+                        for (int m = 0; m < R; m++) wl[m] = gist10[m * 64 + lane];
+                    }
+                }
                 P12<R, G::LR - 1>::inv(re, im, w1.w);
             }
             // now lane holds sub-points q = lane + 64 m of its half.  Last stage (halfnn = 512, spqlios-fft-impl.cpp:346-359):
@@ -336,7 +373,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             if (H == 1) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
-                    const cplx w = gist10[m * 64 + lane];
+                    const cplx w = IST_EARLY ? wl[m] : gist10[m * 64 + lane];
                     const double t0 = re[m] * w.x, t1 = re[m] * w.y, t2 = im[m] * w.x, t3 = im[m] * w.y;
                     re[m] = t0 - t3; im[m] = t1 + t2;
                 }
@@ -353,15 +390,23 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             HALVES_SYNC();
             {
                 uint32_t* poly = accbuf + comp * N;
+                // A: x0 + t, B: x0 - t.  Branch on the half outside the loop: a select would compute both (4 more FP64 instructions per point)
+#ifdef HALVES_CROSS_PAIRED
+#define HALVES_OTX(k) otx[k]
+#else
+#define HALVES_OTX(k) lds_ld(&otx[k])
+#endif
+                if (H) {
+#pragma unroll
+                    for (int m = 0; m < R; m++) { re[m] = HALVES_OTX(lane + 64 * m) - re[m]; im[m] = HALVES_OTX(G::XSLOTS + lane + 64 * m) - im[m]; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < R; m++) { re[m] = re[m] + HALVES_OTX(lane + 64 * m); im[m] = im[m] + HALVES_OTX(G::XSLOTS + lane + 64 * m); }
+                }
+#undef HALVES_OTX
 #pragma unroll
                 for (int m = 0; m < R; m++) {
-#ifdef HALVES_CROSS_PAIRED
-                    const double orr = otx[lane + 64 * m], oi = otx[G::XSLOTS + lane + 64 * m];
-#else
-                    const double orr = lds_ld(&otx[lane + 64 * m]), oi = lds_ld(&otx[G::XSLOTS + lane + 64 * m]);
-#endif
-                    const double vr = H ? orr - re[m] : re[m] + orr;          // A: x0 + t, B: x0 - t
-                    const double vi = H ? oi - im[m] : im[m] + oi;
+                    const double vr = re[m], vi = im[m];
                     // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395)
                     const double rc = vr * wt.w[m].x, ic = vi * wt.w[m].x, rs = vr * wt.w[m].y, is = vi * wt.w[m].y;
                     const int c = lane + 64 * m + 512 * H;

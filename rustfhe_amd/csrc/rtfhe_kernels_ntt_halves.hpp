@@ -145,11 +145,17 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
             for (int m = 0; m < R; m++) myx[lane + 64 * m] = x[m];
             lds_barrier();
             uint32_t* poly = accbuf + comp * N + H * HN;
+            // the branch on the (wave-uniform) half stays outside the point loop (inside it: one branch and one LDS wait per point)
+            if (H) {
+#pragma unroll
+                for (int m = 0; m < R; m++) x[m] = ntt::normalize(ntt::modmul(x[m] - otx[lane + 64 * m], zc));     // zeta_1^-1 (u - v) = zeta_1 (v - u)
+            } else {
+#pragma unroll
+                for (int m = 0; m < R; m++) x[m] = ntt::normalize(x[m] + otx[lane + 64 * m]);
+            }
 #pragma unroll
             for (int m = 0; m < R; m++) {
-                const double o = otx[lane + 64 * m];
-                const double v = H ? ntt::normalize(ntt::modmul(x[m] - o, zc)) : ntt::normalize(x[m] + o);   // zeta_1^-1 (u - v) = zeta_1 (v - u)
-                const uint32_t w = ntt::to_torus(v);
+                const uint32_t w = ntt::to_torus(x[m]);
                 if (CMUX || h == 1) poly[lane + 64 * m] += w;
                 else poly[lane + 64 * m] = w;
             }
