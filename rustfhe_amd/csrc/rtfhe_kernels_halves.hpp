@@ -34,6 +34,9 @@
 #define HALVES_PRIO_B 1      // wave B carries ~9 % more arithmetic (the first-stage / last-stage twiddle products)
 #endif
 
+#ifndef HALVES_B_LOW_MASK
+#define HALVES_B_LOW_MASK 0
+#endif
 #ifndef HALVES_SPLIT_MIN
 #define HALVES_SPLIT_MIN 3   // gates per workgroup from which the two halves trade the first stage's inputs instead of both computing all of them
 #endif
@@ -110,7 +113,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = wave % GATES, H = wave / GATES;          // the two halves of a gate share a SIMD (waves w, w + GATES)
+#ifndef HALVES_MAP
+#define HALVES_MAP 0
+#endif
+    // 0: the two halves of a gate share a SIMD (waves w, w + GATES); 1 / 2 (A/B, 4 gates): as PAIR_MAP in k_bootstrap_pair
+    const int slot = (HALVES_MAP == 1 && GATES == 4) ? wave / 2 : (HALVES_MAP == 2 && GATES == 4) ? 2 * ((wave & 3) >> 1) + (wave >> 2) : wave % GATES;
+    const int H = (HALVES_MAP == 1 && GATES == 4) ? wave % 2 : (HALVES_MAP == 2 && GATES == 4) ? ((wave & 1) ^ (wave >> 2)) : wave / GATES;
     cplx* tw = reinterpret_cast<cplx*>(smem);
     for (int idx = tid; idx < HalvesTw::LDS_FWD; idx += NT) tw[idx] = ha.htw[HalvesTw::ST1 + idx];
     for (int idx = tid; idx < HalvesTw::LDS_INV; idx += NT) tw[HalvesTw::LDS_FWD + idx] = ha.htw[HalvesTw::IP2 + idx];
@@ -203,6 +211,21 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
         __builtin_amdgcn_sched_barrier(0);
     };
     if (H) __builtin_amdgcn_s_setprio(HALVES_PRIO_B);
+    // Priority schedule of wave B: after point p it runs at priority 0 if bit p of HALVES_B_LOW_MASK is set, at HALVES_PRIO_B otherwise (wave A stays at 0; at
+    // equal priority the SIMD favours the older wave, A).  Points: 0 start of a polynomial, 1 after the first stage, 2 after passes 1-2 of the sub-transforms,
+    // 3 after pass 3, 4 after the multiply-accumulate, 5 after an inverse sub-network, 6 after the last stage + accumulator update
+    auto prio_point = [&](int point) {
+        if (HALVES_B_LOW_MASK == 0) return;
+        if ((HALVES_B_LOW_MASK >> point) & 1) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(H) : "scc");
+        else asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio %1\n1:" ::"s"(H), "n"(HALVES_PRIO_B) : "scc");
+    };
+#ifdef RTFHE_WG_STAMPS     // diagnostic builds (scripts/ubench/halves_stamps.py): s_memtime ticks per phase, summed over the steps
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define HV_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[k] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HV_STAMP(k) do { } while (0)
+#endif
 
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
@@ -235,6 +258,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             // arithmetic they save (17.39 vs 17.08 ms per 1024 gates); with the two halves of a gate synchronising with each other only (pair_sync:
             // arrival counters in LDS) it wins where the SIMDs are full -- 4 gates per workgroup 16.87 vs 17.07 ms (60.7 k gates/s), 3 gates 16.26 vs
             // 16.30 -- and loses where they are not (2 gates 13.04 vs 12.24, 1-2 gates 12.90 vs 12.13): on for GATES >= 3.
+            HV_STAMP(6);
+            prio_point(0);
             cplx tH[R];        // twist factors of this half's points, from global memory: requested before the gather they land under
 #pragma unroll
             for (int m = 0; m < R; m++) tH[m] = gtwist[(8 * H + m) * 64];
@@ -246,6 +271,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 uim[m] = ((rotated_coef<LOGN>(poly, c1, r) - poly[c1]) + M) ^ M;
             }
             double xr[R], xi[R];
+            HV_STAMP(0);
             auto own_row = [&](int jj) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
@@ -320,8 +346,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             }
             }
 #endif
+            HV_STAMP(1);
+            prio_point(1);
             // the 512-point sub-transforms of the three rows side by side
             fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, myx, myx + G::XSLOTS, ln);
+            prio_point(2);
 #ifndef HALVES_FETCH_LATE
             fetch(bA, i, h * 2 * L);                    // (row 0, comp 0) of this polynomial: in flight under the last pass
 #endif
@@ -332,6 +361,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             // hadamard + fold-add (spqlios.rs:204-222, trgsw.rs:290-299): this wave's half of the points, component 0 over the
             // polynomial's three rows, then component 1 (each accumulator still folds rows 0..5 in order); two key-row buffers,
             // each refilled as soon as its multiply-accumulate has retired
+            HV_STAMP(2);
+            prio_point(3);
             const int rc0 = h * 2 * L;                  // rc = 2 * row + comp
             fetch(bB, i, rc0 + 2);                                                     // (row 1, c0)
             mac_row<R>(s0re, s0im, bA, yr[0], yi[0]); fetch(bA, i, rc0 + 4);           // (row 2, c0)
@@ -340,6 +371,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             mac_row<R>(s1re, s1im, bB, yr[0], yi[0]); fetch(bB, i, rc0 + 5);           // (row 2, c1)
             mac_row<R>(s1re, s1im, bA, yr[1], yi[1]);
             mac_row<R>(s1re, s1im, bB, yr[2], yi[2]);
+            HV_STAMP(3);
+            prio_point(4);
         }
 
         // inverse: sub-network on this half, last stage across the halves, untwist, truncate, += acc
@@ -368,6 +401,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 }
                 P12<R, G::LR - 1>::inv(re, im, w1.w);
             }
+            HV_STAMP(4);
+            prio_point(5);
             // now lane holds sub-points q = lane + 64 m of its half.  Last stage (halfnn = 512, spqlios-fft-impl.cpp:346-359):
             // t = x1 * w_q; half 0 keeps x0 + t, half 1 keeps x0 - t.  B sends t, A sends x0.
             if (H == 1) {
@@ -415,9 +450,15 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 }
             }
             HALVES_SYNC();     // the partner has read my buffer; both halves of the accumulator are written
+            HV_STAMP(5);
+            prio_point(6);
         }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef RTFHE_WG_STAMPS
+    if (a.dbg && blockIdx.x == 0 && lane0 == 0)
+        for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];
+#endif
 #ifdef ABL_NOKS       // timing ablation only (wrong results)
     if (a.steps >= 0) return;
 #endif

@@ -132,7 +132,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = wave % GATES, side = wave / GATES;
+#ifndef PAIR_MAP
+#define PAIR_MAP 0
+#endif
+    // which gate and side a wave serves.  Waves go to the SIMDs round robin (wave w on SIMD w % 4).  0: the two sides of a gate share a SIMD (waves w, w + GATES);
+    // 1 (A/B, 4 gates): partners on neighbouring SIMDs, a SIMD hosts the same side of two gates; 2 (A/B, 4 gates): partners on neighbouring SIMDs, a SIMD
+    // hosts side 0 of one gate and side 1 of another
+    const int slot = (PAIR_MAP == 1 && GATES == 4) ? wave / 2 : (PAIR_MAP == 2 && GATES == 4) ? 2 * ((wave & 3) >> 1) + (wave >> 2) : wave % GATES;
+    const int side = (PAIR_MAP == 1 && GATES == 4) ? wave % 2 : (PAIR_MAP == 2 && GATES == 4) ? ((wave & 1) ^ (wave >> 2)) : wave / GATES;
     cplx* tw = reinterpret_cast<cplx*>(smem);
     for (int idx = tid; idx < G::TW_TOTAL; idx += NT) tw[idx] = a.tw[idx];
     const cplx* twf = tw;
@@ -234,6 +241,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     // about evenly (measured: profiles/r01_pair/priority_schedule_ab.log).  Points: 0..5 after each half transform,
     // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
     auto prio_point = [&](int point) {   // one opaque statement each: no compiler-visible control flow inside the transforms
+#ifdef PAIR_FLAT_PRIO    // A/B: no schedule, every wave at priority 1
+        return;
+#endif
 #ifdef PAIR_MID_AT
         if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
 #else
@@ -248,7 +258,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         if (point == PAIR_S1_BACK_AT) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
 #endif
     };
+#ifdef PAIR_FLAT_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#else
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
