@@ -103,11 +103,14 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
             double x[R];
+            if (H) {        // branch on the half around the loop (a select inside it computes both sums)
 #pragma unroll
-            for (int m = 0; m < R; m++) {
-                const double d0 = (double)decomp_digit(u0[m], BGBIT, jj);
-                const double tt = t.dig[ntt::digit_entry(u1[m], BGBIT, jj)];     // digit * zeta_1 mod P from the 64-entry table
-                x[m] = H ? d0 - tt : d0 + tt;
+                for (int m = 0; m < R; m++)
+                    x[m] = (double)decomp_digit(u0[m], BGBIT, jj) - t.dig[ntt::digit_entry(u1[m], BGBIT, jj)];     // digit * zeta_1 mod P from the 64-entry table
+            } else {
+#pragma unroll
+                for (int m = 0; m < R; m++)
+                    x[m] = (double)decomp_digit(u0[m], BGBIT, jj) + t.dig[ntt::digit_entry(u1[m], BGBIT, jj)];
             }
             double2 b0[R / 2], b1[R / 2];
             ntt::forward_a(x, t.fwd, myx, lane);
