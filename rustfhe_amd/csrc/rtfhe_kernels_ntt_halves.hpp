@@ -44,7 +44,8 @@ struct NttHalvesLds {
     static constexpr size_t XB = (size_t)ntt::XSLOTS * sizeof(double);
     static_assert(ntt::XSLOTS >= ntt::N, "an exchange buffer must hold one half");
     __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB; }
+    static constexpr size_t FLAGS = 16;       // two arrival counters per gate (pair_sync)
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB + FLAGS; }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
@@ -68,10 +69,16 @@ __device__ __forceinline__ void ntt_halves_load_tables(double* lds, const double
 
 // One external product (CMUX = false: acc <- BK_i (x) acc) or one CMUX step (acc += BK_i (x) ((X^r - 1) acc)) by the two waves of a
 // gate.  Every wave of the workgroup must call it (workgroup barriers inside).
-template <int L, int BGBIT, bool CMUX>
+// PAIRSYNC: the two halves synchronise with each other only (pair_sync on the gate's arrival counters: my_flag / partner_flag are their LDS
+// addresses, sync_k the running count) instead of the workgroup barrier.
+template <int L, int BGBIT, bool CMUX, bool PAIRSYNC = false>
 __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const __amdgpu_buffer_rsrc_t bk_rsrc, int bk_off,
                                                 const NttHalvesTables& t, double* __restrict__ myx, const double* __restrict__ otx,
-                                                int lane0, int H) {
+                                                int lane0, int H, unsigned my_flag = 0, unsigned partner_flag = 0, unsigned* sync_k = nullptr) {
+    auto halves_sync = [&]() {
+        if constexpr (PAIRSYNC) pair_sync(my_flag, partner_flag, ++*sync_k);
+        else lds_barrier();
+    };
     constexpr int LOGN = 11, N = 2048, HN = 1024, R = ntt::R;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert((1 << BGBIT) == ntt::DIGITS, "the digit table has one entry per digit value");
@@ -146,7 +153,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
             // x[m] = sub-coefficient lane + 64 m of this half (u on wave 0, v on wave 1), |x| <= P/2
 #pragma unroll
             for (int m = 0; m < R; m++) myx[lane + 64 * m] = x[m];
-            lds_barrier();
+            halves_sync();
             uint32_t* poly = accbuf + comp * N + H * HN;
             // the branch on the (wave-uniform) half stays outside the point loop (inside it: one branch and one LDS wait per point)
             if (H) {
@@ -162,7 +169,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
                 if (CMUX || h == 1) poly[lane + 64 * m] += w;
                 else poly[lane + 64 * m] = w;
             }
-            lds_barrier();      // the partner has read my buffer; both halves of the polynomial are written
+            halves_sync();      // the partner has read my buffer; both halves of the polynomial are written
         }
     }
 }
@@ -197,6 +204,17 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
     double* xb1 = xb0 + ntt::XSLOTS;
     double* myx = H ? xb1 : xb0;
     const double* otx = H ? xb0 : xb1;
+    // arrival counters of the two halves of this gate (zeroed before the start-up barriers)
+#ifdef NTT_HALVES_WG_BARRIER      // A/B: the workgroup-wide barrier (round 2)
+    constexpr bool PAIRSYNC = false;
+#else
+    constexpr bool PAIRSYNC = GATES >= 2;     // 1024 gates 31.30 -> 31.06 ms, 512 gates 19.70 -> 19.25; one gate per workgroup 18.22 -> 18.34: off there
+#endif
+    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + NttHalvesLds::gate_bytes(a.npad) - NttHalvesLds::FLAGS);
+    if (lane0 == 0) flags[H] = 0u;
+    const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + H);
+    const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - H));
+    unsigned sync_k = 0;
 
     const int n = a.n;
     {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(args.ntt_bk + (size_t)i * trgsw_doubles), 0,
                                                                             (int)(trgsw_doubles * 8), 0x00020000);
-        ntt_halves_step<L, BGBIT, true>(accbuf, r, rs, 0, tables, myx, otx, lane0, H);
+        ntt_halves_step<L, BGBIT, true, PAIRSYNC>(accbuf, r, rs, 0, tables, myx, otx, lane0, H, my_flag, partner_flag, &sync_k);
     }
 
     if (a.mode == MODE_BLIND_ROTATE) {
