@@ -189,68 +189,198 @@ def launch(args):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only): the oracle / the reference's own FFT on the host cores.  Checker, never product.
 # ------------------------------------------------------------------------------------------------------------------
-def host_cores():
-    """(physical cores, hardware threads) this process may run on: os.sched_getaffinity gives hardware threads (SMT siblings
-    included); physical cores = distinct (physical id, core id) pairs of those threads in /proc/cpuinfo."""
-    threads = sorted(os.sched_getaffinity(0))
-    cores = set()
+def _signal_name(rc):
+    import signal
+    if rc is None or rc >= 0:
+        return None
     try:
-        cur = {}
-        with open("/proc/cpuinfo") as f:
-            for ln in f.read().split("\n") + [""]:
-                if ":" in ln:
-                    k, v = ln.split(":", 1)
-                    cur[k.strip()] = v.strip()
-                elif cur:
-                    if int(cur.get("processor", -1)) in threads:
-                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
-                    cur = {}
-    except OSError:
-        pass
-    return (len(cores) or len(threads)), len(threads)
+        return signal.Signals(-rc).name
+    except ValueError:
+        return "signal %d" % -rc
 
 
-def cpu_baseline(R, params, key_bk_t, ksk, in0, in1, gpu_out, per_thread):
+def cpu_baseline_child(tmpdir, per_thread):
+    """The CPU baseline leg, run as a FRESH PROCESS that never loads the HIP library or torch: a native crash in the oracle / the
+    reference-built spqlios (an instruction this host lacks, a fault) costs this process, not the bench line.  Protocol: the parent
+    (rank 0, before its first GPU call) writes params / keys / inputs to `tmpdir` and starts this; it sets itself up (loads the
+    oracle, transforms the key) and blocks on stdin; the parent, once its timed region is over, writes gpu_out.npy and sends "go";
+    this measures and prints ONE JSON object on stdout.  EOF instead of "go" = exit quietly.
+
+    What is measured: first the single-thread rate on an otherwise idle host (16 gates, thread pinned); then
+    all-core runs in which EVERY thread gets `per_thread` gates or more (the batch's 1024 inputs are tiled: gate g takes input
+    g % 1024 and is compared with GPU output g % 1024), threads pinned, the two 62 MB keys replicated per memory node and
+    first-touched by a thread of that node (oracle/tfhe_oracle.c: orc_gate_batch_mt_numa) -- once with one thread per physical
+    core and once with one per hardware thread (and once with as many threads as the cgroup's CPU quota allows, when that is
+    less); the best is `value`.  scaling_efficiency = value / (threads_used' cores x the single-thread rate)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
+    import math
     import numpy as np
     import orc
-    cores, threads = host_cores()
-    sample = min(len(in0), threads * per_thread)
-    single = min(len(in0), 16)
-    p = orc.Params(n=params.n, N=params.N, l=params.l, bgbit=params.bgbit, ks_t=params.ks_t, ks_basebit=params.ks_basebit)
+    z = np.load(os.path.join(tmpdir, "inputs.npz"))
+    pr = [int(v) for v in z["params"]]
+    p = orc.Params(n=pr[0], N=pr[1], l=pr[2], bgbit=pr[3], ks_t=pr[4], ks_basebit=pr[5])
+    bk, ksk, in0, in1 = z["bk"], z["ksk"], z["in0"], z["in1"]
     pl = orc.Plan(p.N)
-    bk_f = np.empty(key_bk_t.size, np.float64)
-    orc.lib().orc_trgsw_to_fft(pl.h, key_bk_t.ctypes.data_as(C.POINTER(C.c_uint32)),
-                               bk_f.ctypes.data_as(C.POINTER(C.c_double)), key_bk_t.size // p.N)
-    timing = "timed from the moment every thread holds its FFT plan to the last thread's last gate (thread and plan creation outside)"
-    # the single-thread figure first, on an otherwise idle host (after the all-thread run the package is still clocked down)
-    one, secs1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:single], in1[:single], 1)
-    out, secs = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:sample], in1[:sample], threads)
-    port = {
-        "value": round(sample / secs, 2), "unit": "gates/s", "cores": cores, "hw_threads": threads, "threads_used": threads, "kind": "port",
-        "sample": "%d NAND gates of the same batch (%d per thread, one independent gate stream per thread on each of the %d hardware "
-                  "threads of %d physical cores), oracle/tfhe_oracle.c FP64 mirror of the reference spqlios FFT, "
-                  "gcc -O3 -march=native -ffp-contract=off; %s" % (sample, per_thread, threads, cores, timing),
-        "seconds": round(secs, 2), "single_thread_ms_per_gate": round(1e3 * secs1 / single, 2), "single_thread_sample_gates": single,
-        "matches_gpu_bit_exact": bool(np.array_equal(out, gpu_out[:sample])),
-    }
-    if not orc.have_ref():
-        return port
-    # the reference's OWN compiled native FFT (oracle/_ref: utils/src/spqlios/*.cpp + AVX .s built with its build.rs flags)
-    # under the restated Rust glue (the Rust half cannot be built here: no toolchain); one handle per thread
-    orc.use_reference_fft_in_mt()
-    one_r, secs_r1 = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:single], in1[:single], 1, backend=orc.BACKEND_HOOK)
-    out_r, secs_r = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0[:sample], in1[:sample], threads, backend=orc.BACKEND_HOOK)
-    return {
-        "value": round(sample / secs_r, 2), "unit": "gates/s", "cores": cores, "hw_threads": threads, "threads_used": threads, "kind": "reference",
-        "sample": "%d NAND gates of the same batch (%d per thread, one gate stream + one Spqlios handle per thread on each of the %d "
-                  "hardware threads of %d physical cores): the reference's own compiled spqlios AVX FFT (oracle/_ref, flags of "
-                  "utils/build.rs) under the C restatement of its Rust glue; %s" % (sample, per_thread, threads, cores, timing),
-        "seconds": round(secs_r, 2), "single_thread_ms_per_gate": round(1e3 * secs_r1 / single, 2), "single_thread_sample_gates": single,
-        "matches_gpu_bit_exact": bool(np.array_equal(out_r, gpu_out[:sample])),
-        "port": port,
-    }
+    bk_f = np.empty(bk.size, np.float64)
+    orc.lib().orc_trgsw_to_fft(pl.h, bk.ctypes.data_as(C.POINTER(C.c_uint32)), bk_f.ctypes.data_as(C.POINTER(C.c_double)), bk.size // p.N)
+    del bk
+    topo = orc.host_topology()
+    have_ref = orc.have_ref()
+    if have_ref:
+        orc.use_reference_fft_in_mt()
+    if not sys.stdin.readline().startswith("go"):
+        return 0
+    if os.environ.get("RTFHE_BENCH_TEST_ABORT") == "cpu_child":       # tests: the headline must survive this
+        os.abort()
+    gpu_out = np.load(os.path.join(tmpdir, "gpu_out.npy"))
+    in_count = in0.shape[0]
+    per_core, per_hw = topo["one_thread_per_core"], topo["hw_threads"]
+    quota = topo["cgroup_cpu_quota"]
+    single = min(in_count, 16)
+    target_s = float(os.environ.get("RTFHE_BENCH_CPU_TARGET_S", "2.5"))      # seconds an all-core run lasts at perfect scaling (tests shorten it)
+
+    def leg(backend):
+        # single thread first, on an otherwise idle host (after an all-core run the package is still clocked down)
+        out1, s1 = orc.gate_batch_mt_numa(p, orc.NAND, bk_f, ksk, in0[:single], in1[:single], single, per_core[:1], topo["node_of"], backend=backend)
+        rate1 = single / s1
+        ok = bool(np.array_equal(out1, gpu_out[:single]))
+        sets = [("one_thread_per_physical_core", per_core, True)]
+        if len(per_hw) > len(per_core):
+            sets.append(("one_thread_per_hardware_thread", per_hw, True))
+        if quota and quota < len(per_core):
+            sets.append(("cgroup_cpu_quota_threads_unpinned", per_core[:max(1, int(math.ceil(quota)))], False))
+        runs = []
+        for name, cpus, pin in sets:
+            # at least per_thread gates per thread, and enough for ~2.5 s at perfect scaling (bounded: the whole leg stays within ~30 s)
+            k = int(min(512, max(per_thread, math.ceil(target_s * rate1))))
+            count = k * len(cpus)
+            out, secs = orc.gate_batch_mt_numa(p, orc.NAND, bk_f, ksk, in0, in1, count, cpus, topo["node_of"], backend=backend, pin=pin)
+            same = bool(np.array_equal(out, gpu_out[np.arange(count) % in_count]))
+            ok = ok and same
+            ncores = len(set(topo["core_of"][c] for c in cpus))       # physical cores the threads occupy
+            runs.append({"threads": name, "threads_used": len(cpus), "pinned": pin, "gates": count, "gates_per_thread": k, "seconds": round(secs, 3),
+                         "gates_per_s": round(count / secs, 1), "cores_busy": ncores,
+                         "scaling_efficiency": round(count / secs / (ncores * rate1), 3), "matches_gpu_bit_exact": same})
+            del out
+        best = max(runs, key=lambda r: r["gates_per_s"])
+        return rate1, runs, best, ok
+
+    timing = "timed from the moment every thread holds its FFT plan and every memory node its key replica to the last thread's last gate"
+    nodes = len(topo["nodes"])
+    host = {"cpu_model": topo["cpu_model"], "physical_cores": len(per_core), "hw_threads": len(per_hw), "memory_nodes": nodes,
+            "cgroup_cpu_quota_cores": quota}
+    rate1, runs, best, ok = leg(orc.BACKEND_MIRROR)
+    port = {"value": best["gates_per_s"], "unit": "gates/s", "cores": len(per_core), "hw_threads": len(per_hw), "threads_used": best["threads_used"],
+            "kind": "port", "single_thread_ms_per_gate": round(1e3 / rate1, 2), "single_thread_sample_gates": single,
+            "scaling_efficiency": best["scaling_efficiency"], "runs": runs, "matches_gpu_bit_exact": ok,
+            "sample": "%d NAND gates (%d per thread on %d pinned threads, the batch's %d inputs tiled, every output compared with the GPU's), "
+                      "oracle/tfhe_oracle.c FP64 mirror of the reference spqlios FFT, gcc -O3 -march=x86-64-v3 -ffp-contract=off, keys replicated "
+                      "on each of %d memory node(s); %s" % (best["gates"], best["gates_per_thread"], best["threads_used"], in_count, nodes, timing)}
+    res = port
+    if have_ref:
+        # the reference's OWN compiled native FFT (oracle/_ref: utils/src/spqlios/*.cpp + AVX .s) under the restated Rust glue
+        # (the Rust half cannot be built: no toolchain); one Spqlios handle per thread, as its thread_local FFT_MAP would give
+        rate1r, runs_r, best_r, ok_r = leg(orc.BACKEND_HOOK)
+        res = {"value": best_r["gates_per_s"], "unit": "gates/s", "cores": len(per_core), "hw_threads": len(per_hw), "threads_used": best_r["threads_used"],
+               "kind": "reference", "single_thread_ms_per_gate": round(1e3 / rate1r, 2), "single_thread_sample_gates": single,
+               "scaling_efficiency": best_r["scaling_efficiency"], "runs": runs_r, "matches_gpu_bit_exact": ok_r,
+               "sample": "%d NAND gates (%d per thread on %d pinned threads, the batch's %d inputs tiled, every output compared with the GPU's): the "
+                         "reference's own compiled spqlios AVX FFT (oracle/_ref, flags of utils/build.rs with -march pinned to x86-64-v3), one handle "
+                         "per thread, under the C restatement of its Rust glue, keys replicated on each of %d memory node(s); %s"
+                         % (best_r["gates"], best_r["gates_per_thread"], best_r["threads_used"], in_count, nodes, timing),
+               "port": port}
+        rate1, best = rate1r, best_r
+    res["host"] = host
+    # the bound the all-core figure sits under: every gate streams the key spectra and the touched key-switching rows from memory
+    try:
+        cpus = per_core if best["threads_used"] <= len(per_core) else per_hw
+        bw = orc.stream_read_bandwidth(cpus, 128 << 20, 2)
+        res["memory"] = {"stream_read_GBps": round(bw / 1e9, 1), "bytes_per_gate": ALG_BYTES_PER_GATE,
+                         "gates_per_s_at_that_bandwidth": round(bw / ALG_BYTES_PER_GATE, 1),
+                         "note": "sustained read bandwidth of %d pinned threads over private 128 MiB buffers; a gate streams %.1f MB of keys, so the "
+                                 "all-core rate cannot exceed bandwidth / bytes per gate whatever the core count" % (len(cpus), ALG_BYTES_PER_GATE / 1e6)}
+    except Exception as e:          # noqa: BLE001
+        res["memory"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    print(json.dumps(res), flush=True)
+    return 0
+
+
+class CpuBaselineChild:
+    """Parent side of cpu_baseline_child: start() BEFORE the first GPU call, collect() after the timed region."""
+
+    def __init__(self, np, params, bk, ksk, in0, in1, per_thread):
+        import tempfile
+        self.np = np
+        self.dir = tempfile.mkdtemp(prefix="rtfhe_bench_")
+        np.savez(os.path.join(self.dir, "inputs.npz"), params=np.array([params.n, params.N, params.l, params.bgbit, params.ks_t, params.ks_basebit], np.int64),
+                 bk=bk, ksk=ksk, in0=in0, in1=in1)
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", self.dir, "--cpu-gates-per-thread", str(per_thread)],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+    def collect(self, gpu_out, timeout=420):
+        try:
+            self.np.save(os.path.join(self.dir, "gpu_out.npy"), gpu_out)
+            try:
+                out, _ = self.proc.communicate("go\n", timeout=timeout)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()
+                self.proc.communicate()
+                return {"error": "the CPU baseline child did not finish within %d s and was killed" % timeout}
+            rc = self.proc.returncode
+            if rc != 0:
+                return {"error": "the CPU baseline child exited with %s%s" % (rc, " (%s)" % _signal_name(rc) if rc < 0 else ""), "rc": rc}
+            for ln in reversed(out.strip().split("\n")):
+                try:
+                    return json.loads(ln)
+                except ValueError:
+                    continue
+            return {"error": "the CPU baseline child printed no JSON"}
+        finally:
+            self.close()
+
+    def close(self):
+        import shutil
+        if self.proc.poll() is None:
+            try:
+                self.proc.stdin.close()         # EOF instead of "go": the child exits quietly
+                self.proc.wait(timeout=20)
+            except Exception:                   # noqa: BLE001
+                self.proc.kill()
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# supervisor (N = 1, plain `python bench.py`): the measuring process runs as a child; the headline survives its death
+# ------------------------------------------------------------------------------------------------------------------
+def supervise(child_cmd, env=None):
+    """Runs the measuring process as a child with RTFHE_BENCH_INNER=1 and prints exactly ONE JSON line: the LAST complete line the
+    child produced.  The child prints its line as soon as the headline is complete (marked "provisional") and again after each side
+    leg (CPU baseline, secondary measurements); if it then dies -- a native crash in a side kernel, an abort() in a library -- the
+    headline measured before is printed with the crash recorded in it, and the exit code is 0.  No line at all = the child's exit code."""
+    e = dict(os.environ if env is None else env)
+    e["RTFHE_BENCH_INNER"] = "1"
+    proc = subprocess.Popen(list(child_cmd), stdout=subprocess.PIPE, text=True, env=e)
+    last = None
+    for ln in proc.stdout:
+        try:
+            j = json.loads(ln)
+        except ValueError:
+            sys.stderr.write(ln)             # stray text never reaches our stdout
+            continue
+        if isinstance(j, dict) and "metric" in j:
+            last = j
+    rc = proc.wait()
+    if last is None:
+        sys.stderr.write("bench.py: the measuring process exited with %s and printed no line\n" % rc)
+        return rc if rc > 0 else 1
+    pending = last.pop("provisional", None)
+    if rc != 0:
+        last["side_leg_crash"] = {"rc": rc, "signal": _signal_name(rc), "legs_not_completed": pending,
+                                  "note": "the measuring process died AFTER the headline above was complete; the value, roofline and every leg "
+                                          "present in this line were measured before that"}
+    print(json.dumps(last), flush=True)
+    return 0
 
 
 def fp64_frac(dp_per_cmux, n, gates, seconds):
@@ -355,6 +485,22 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
         sec["ntt_exact_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_ntt_pair",
                                        "roofline_frac_fp64": fp64_frac(nops, params.n, G, ms * 1e-3), "ok": okn}
     guard("ntt_exact_1024_gates", _ntt_exact_1024_gates)
+    # -- tail behaviour on the driver's clock: batches that do not fill whole rounds of 4 gates per CU (default dispatch: a remainder of
+    #    <= 1 gate per CU on the latency shape, <= 2 / <= 3 per CU on 2 / 3 gates per workgroup); two untimed launches, then three timed
+    def _batch_sweep():
+        sizes = (256, 512, 768, 1280, 1536)
+        Gm = max(sizes)
+        bb = rng.integers(0, 2, (2, Gm)).astype(np.uint8)
+        s0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 61).view(np.int32)).to(gpu)
+        s1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 62).view(np.int32)).to(gpu)
+        so = torch.empty_like(s0)
+        sweep = {}
+        for Gs in sizes:
+            ms, ks = timed(eng, lambda: eng.gate_batch_dev(R.NAND, s0, s1, so, Gs, stream), 3)
+            oks = bool(np.array_equal(R.decrypt_bits(params, key0, so[:Gs].cpu().numpy().view(np.uint32)), 1 - (bb[0][:Gs] & bb[1][:Gs])))
+            sweep[str(Gs)] = {"gates_per_s": round(Gs / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "key_switch_ms": round(ks, 3), "ok": oks}
+        sec["batch_sweep"] = sweep
+    guard("batch_sweep", _batch_sweep)
     # -- BASELINE configs[4]: N = 2048, 1024 gates (its own key set and context)
     def _config5_n2048_1024_gates():
         G = 1024
@@ -380,6 +526,28 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
     return sec
 
 
+def cargo_probe():
+    """"if cargo exists on the GPU box, additionally run the reference's homnand-bench".  The reference checkout never travels
+    to the GPU box, so what a toolchain there can do is build the shipped shim crates (bindings/rust) against this library; absent
+    toolchain = "absent" in the line.  Never fatal."""
+    import shutil
+    cargo = shutil.which("cargo")
+    if not cargo:
+        return "absent"
+    res = {"cargo": cargo}
+    try:
+        res["version"] = subprocess.run([cargo, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+        crate = os.path.join(ROOT, "bindings", "rust", "rtfhe-sys")
+        r = subprocess.run([cargo, "build", "--release", "--offline"], cwd=crate, capture_output=True, text=True, timeout=180,
+                           env=dict(os.environ, RTFHE_LIB_DIR=os.path.join(ROOT, "rustfhe_amd")))
+        res["rtfhe_sys_build_rc"] = r.returncode
+        if r.returncode != 0:
+            res["rtfhe_sys_build_stderr_tail"] = r.stderr[-400:]
+    except Exception as e:          # noqa: BLE001
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------------------------
@@ -392,12 +560,45 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    inner = bool(os.environ.get("RTFHE_BENCH_INNER"))       # our stdout is read by supervise(): intermediate lines are welcome
     # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to stdout when its first communicator comes up
     # (seen on ROCm 7: "RCCL version : ...", 5 lines).  Until the line is printed, file descriptor 1 points at stderr.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
+    config3 = args.workload == "config3"
+    mirror = args.backend == "fft64-mirror"
+    G = args.gates if args.gates else (8192 if config3 else 1024)      # gates per GPU per step
+    params = R.Params()
+    # ---- everything that needs no GPU comes first: keys (rank 0), this rank's inputs, and -- N = 1 only -- the CPU baseline's own
+    # process, started BEFORE this process makes its first GPU call and left waiting on its stdin until the timed region is over
+    t_key = time.perf_counter()
+    if rank == 0:
+        key0, key1, bk, ksk = R.keygen(params, 20211003)
+    else:
+        key0, bk, ksk = np.empty(params.n, np.int32), np.empty(params.bk_words, np.uint32), np.empty(params.ksk_words, np.uint32)
+    cpu_child = None
+    want_cpu = world == 1 and not args.no_cpu_baseline and mirror and not config3
+    if want_cpu:
+        rng = np.random.default_rng(1000 + rank)
+        b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
+        in0 = R.encrypt_bits(params, key0, b0, 5000 + 2 * rank)
+        in1 = R.encrypt_bits(params, key0, b1, 5001 + 2 * rank)
+        try:
+            cpu_child = CpuBaselineChild(np, params, bk, ksk, in0, in1, args.cpu_gates_per_thread)
+        except Exception as e:          # noqa: BLE001
+            cpu_child = {"error": "could not start the CPU baseline child: %s: %s" % (type(e).__name__, e)}
+
     if not torch.cuda.is_available():
+        if isinstance(cpu_child, CpuBaselineChild):
+            cpu_child.close()
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # RTFHE_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("RTFHE_BENCH_BACKEND", "nccl")
@@ -427,17 +628,19 @@ def run_rank(args):
         # one line per rank on stderr: enough to read a first multi-GPU run from its log (which card, which peers it can reach over
         # xGMI / P2P, what the communicator looks like)
         peers = [d for d in range(ndev) if d != dev and torch.cuda.can_device_access_peer(dev, d)]
-        sys.stderr.write("bench.py rank %d/%d: device %d of %d (%s), backend %s, communicator world size %d, P2P-reachable peers %s, "
-                         "HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (rank, world, dev, ndev, torch.cuda.get_device_name(dev), backend, n_gpus, peers,
+        props = torch.cuda.get_device_properties(dev)
+        ident = "%s/%s" % (getattr(props, "uuid", ""), getattr(props, "pci_bus_id", dev))
+        sys.stderr.write("bench.py rank %d/%d: device %d of %d (%s, %s), backend %s, communicator world size %d, P2P-reachable peers %s, "
+                         "HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (rank, world, dev, ndev, torch.cuda.get_device_name(dev), ident, backend, n_gpus, peers,
                                                               os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+        # a whole-node number is only a whole-node number if every rank drives a card of its own: under RCCL the ranks compare device
+        # identities and the job refuses to print a line when two of them share one
+        idents = [None] * n_gpus
+        dist.all_gather_object(idents, ident)
+        if backend == "nccl" and len(set(idents)) != n_gpus:
+            raise SystemExit("bench.py: %d ranks but only %d distinct GPUs (%s): no line is printed for such a run" % (n_gpus, len(set(idents)), sorted(set(idents))))
 
-    # ---- keys: generated ONCE (rank 0) and broadcast to the other ranks (RCCL), then loaded into each rank's engine ----
-    params = R.Params()
-    t_key = time.perf_counter()
-    if rank == 0:
-        key0, key1, bk, ksk = R.keygen(params, 20211003)
-    else:
-        key0, bk, ksk = np.empty(params.n, np.int32), np.empty(params.bk_words, np.uint32), np.empty(params.ksk_words, np.uint32)
+    # ---- keys: generated ONCE (rank 0, above) and broadcast to the other ranks (RCCL), then loaded into each rank's engine ----
     if dist is not None:
         for arr in (key0, bk, ksk):
             t = torch.from_numpy(arr.view(np.int32)).to(comm)
@@ -452,8 +655,6 @@ def run_rank(args):
     if args.backend == "ntt-exact":
         eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
 
-    config3 = args.workload == "config3"
-    G = args.gates if args.gates else (8192 if config3 else 1024)      # gates per GPU per step
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -462,6 +663,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     phase = None
+    settle = 0
     if config3:
         # the WHOLE batch (G gates per GPU) starts as ciphertexts in rank 0's HBM and the results end there
         total = G * world
@@ -493,13 +695,26 @@ def run_rank(args):
             out = res.cpu().numpy().view(np.uint32)
             ok = bool(np.array_equal(R.decrypt_bits(params, key0, out), 1 - (b0 & b1)))
     else:
-        rng = np.random.default_rng(1000 + rank)
-        b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
-        in0 = R.encrypt_bits(params, key0, b0, 5000 + 2 * rank)
-        in1 = R.encrypt_bits(params, key0, b1, 5001 + 2 * rank)
+        if not want_cpu:
+            rng = np.random.default_rng(1000 + rank)
+            b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
+            in0 = R.encrypt_bits(params, key0, b0, 5000 + 2 * rank)
+            in1 = R.encrypt_bits(params, key0, b1, 5001 + 2 * rank)
         d_in0 = torch.from_numpy(in0.view(np.int32)).to(gpu)
         d_in1 = torch.from_numpy(in1.view(np.int32)).to(gpu)
         d_out = torch.empty_like(d_in0)
+        # Clock settle (set-up, like the key load; never timed): the first launches after idle run at a lower clock (rocprofv3 of round 3:
+        # 8.0 -> 6.4 ms over five launches).  Untimed launches until three in a row agree within 1 %, at most SETTLE_MAX; the W warm-up steps
+        # the caller asked for follow, then the K timed ones.  The count is reported in config.clock_settle_launches; --settle-max 0 turns it off.
+        settle, recent = 0, []
+        while settle < args.settle_max:
+            eng.timer_begin(stream)
+            eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
+            ms1, _ = eng.timer_end(stream)
+            settle += 1
+            recent = (recent + [ms1])[-3:]
+            if len(recent) == 3 and max(recent) <= 1.01 * min(recent):
+                break
         for _ in range(args.warmup):
             eng.gate_batch_dev(R.NAND, d_in0, d_in1, d_out, G, stream)
         barrier()
@@ -537,7 +752,8 @@ def run_rank(args):
                        "params": "N=1024, n=635, l=3, Bgbit=6, ks t=8 basebit=2", "gates_per_gpu": G, "backend": args.backend,
                        "sharding": "contiguous gate ranges, replicated keys (generated on rank 0, broadcast); " +
                                    ("P2P scatter/gather of ciphertexts only" if config3 else "no data-path collective"),
-                       "comm_backend": (backend if dist is not None else None), "key_setup_s": round(key_s, 2)},
+                       "comm_backend": (backend if dist is not None else None), "key_setup_s": round(key_s, 2),
+                       "clock_settle_launches": settle},
             "outputs_decrypt_correctly": ok and bad == 0.0,
         }
         if phase:
@@ -595,22 +811,40 @@ def run_rank(args):
                 line["roofline"]["traffic_measured_in_this_run"] = False     # a builder-side rocprofv3 --pmc profile of the same device code
             else:
                 line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json is from other device code or another launch shape: not quoted"
-        # the headline above is complete at this point: a failure in one of the side measurements must not cost the line
-        if n_gpus == 1 and not args.no_cpu_baseline and mirror and not config3:
-            try:
-                line["cpu_baseline"] = cpu_baseline(R, params, bk, ksk, in0, in1, out, args.cpu_gates_per_thread)
-            except Exception as e:          # noqa: BLE001
-                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if n_gpus == 1 and not args.no_secondary and mirror and not config3 and not args.gates:
-            # the other BASELINE configs + the NTT backend on the same clock (headline fields above are not touched by this)
+        # The headline above is complete at this point, and nothing below may cost it.  Under supervise() (plain `python bench.py`, N = 1) the
+        # line goes out NOW, marked provisional, and again after every side leg: if this process then dies of a native crash in a side
+        # kernel or library, the supervisor prints the last line it saw and exits 0.  The CPU baseline runs in a process of its own.
+        line["cargo"] = cargo_probe()
+        pending = []
+        if isinstance(cpu_child, (CpuBaselineChild, dict)):
+            pending.append("cpu_baseline")
+        want_secondary = n_gpus == 1 and not args.no_secondary and mirror and not config3 and not args.gates
+        if want_secondary:
+            pending.append("secondary")
+
+        def progress():
+            if inner and pending:
+                emit(dict(line, provisional=list(pending)))
+        progress()
+        if isinstance(cpu_child, dict):
+            line["cpu_baseline"] = cpu_child
+            pending.remove("cpu_baseline")
+        elif cpu_child is not None:
+            line["cpu_baseline"] = cpu_child.collect(out)
+            pending.remove("cpu_baseline")
+            progress()
+        if want_secondary:
+            # the other BASELINE configs + the NTT backend + the batch sweep on the same clock (headline fields above are not touched by this)
+            if os.environ.get("RTFHE_BENCH_TEST_ABORT") == "secondary":       # tests: the headline must survive this
+                os.abort()
             try:
                 line["secondary"] = secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np)
             except Exception as e:          # noqa: BLE001
                 line["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+            pending.remove("secondary")
+        emit(line)
+    elif isinstance(cpu_child, CpuBaselineChild):
+        cpu_child.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -630,12 +864,19 @@ def main():
                     help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs / NTT backend measured after the headline")
-    ap.add_argument("--cpu-gates-per-thread", type=int, default=24)
+    ap.add_argument("--cpu-gates-per-thread", type=int, default=24, help="least number of gates every thread of the all-core CPU baseline runs")
+    ap.add_argument("--settle-max", type=int, default=16, help="most untimed clock-settle launches before the warm-up steps (0: none)")
+    ap.add_argument("--cpu-baseline-child", metavar="DIR", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        sys.exit(cpu_baseline_child(args.cpu_baseline_child, args.cpu_gates_per_thread))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args))                      # parent: spawn the ranks, never touch the GPU
+    if "WORLD_SIZE" not in os.environ and not os.environ.get("RTFHE_BENCH_INNER"):
+        # N = 1, started by hand or by the driver: this process only supervises (never imports torch, never touches the GPU)
+        sys.exit(supervise([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used\n" % (args.gpus, os.environ["WORLD_SIZE"]))
     run_rank(args)

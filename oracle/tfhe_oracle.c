@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -621,6 +622,151 @@ double orc_gate_batch_mt(const orc_params *p, int backend, int op, const double 
     pthread_barrier_destroy(&ready);
     free(th); free(jobs);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* The all-core CPU baseline of bench.py (round 4).  What differs from orc_gate_batch_mt:
+ *  - `count` gates are run over `in_count` distinct inputs (gate g takes input g % in_count and writes out[g]): a thread gets tens of gates,
+ *    not a handful, so ramp-up and stragglers stop dominating the figure;
+ *  - every thread may be pinned to one CPU (cpus[t] >= 0), and the bootstrapping key spectra and the key-switching key (62 MB each, streamed
+ *    once per gate by every thread) are replicated per memory node: node_of_thread[t] names the replica thread t reads, and the FIRST thread
+ *    of a node allocates and fills that replica itself, i.e. first-touches it on its own node (Linux places a page on the node of the thread
+ *    that first writes it).  One copy first-touched by the main thread -- round 3 -- made every core of the other sockets stream it across
+ *    the inter-socket links.
+ * The reference's own threading model would be exactly this: `&self` keys shared read-only, one FFT plan per thread (thread_local! FFT_MAP,
+ * utils/src/math.rs:349-351).  Returns the seconds from the moment every thread holds its plan and every replica is filled to the last
+ * thread's last gate; -1.0 on allocation failure. */
+typedef struct {
+    const orc_params *p; int backend; int op; const double *bk_f; size_t bk_doubles; const uint32_t *ksk; size_t ksk_words;
+    const uint32_t *in0, *in1; uint32_t *out; size_t in_count, begin, end;
+    int cpu, node, leader;
+    double **rep_bk; uint32_t **rep_ksk;        /* per node, filled by the node's leader */
+    pthread_barrier_t *filled, *ready;
+    int *fail;
+} numa_job;
+
+static void *numa_worker(void *arg) {
+    numa_job *j = (numa_job *)arg;
+    if (j->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(j->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);      /* best effort: a refused mask leaves the thread where it is */
+    }
+    if (j->leader) {
+        double *b = (double *)malloc(sizeof(double) * j->bk_doubles);
+        uint32_t *k = (uint32_t *)malloc(sizeof(uint32_t) * j->ksk_words);
+        if (b && k) {
+            memcpy(b, j->bk_f, sizeof(double) * j->bk_doubles);          /* first touch: on this thread's node */
+            memcpy(k, j->ksk, sizeof(uint32_t) * j->ksk_words);
+        } else {
+            *j->fail = 1;
+        }
+        j->rep_bk[j->node] = b;
+        j->rep_ksk[j->node] = k;
+    }
+    orc_plan *pl = orc_plan_new(j->p->N);
+    orc_plan_set_backend(pl, j->backend);
+    if (j->backend == ORC_BACKEND_HOOK && g_mt_new) orc_plan_set_hooks(pl, g_mt_new(j->p->N), g_mt_fwd, g_mt_inv);
+    pthread_barrier_wait(j->filled);
+    const double *bk = j->rep_bk[j->node];
+    const uint32_t *ks = j->rep_ksk[j->node];
+    const size_t w = (size_t)j->p->n + 1;
+    pthread_barrier_wait(j->ready);
+    if (!*j->fail)
+        for (size_t g = j->begin; g < j->end; g++) {
+            const size_t s = g % j->in_count;
+            orc_gate(j->p, pl, j->op, bk, NULL, ks, j->in0 + s * w, j->in1 ? j->in1 + s * w : NULL, j->out + g * w);
+        }
+    orc_plan_free(pl);
+    return NULL;
+}
+
+double orc_gate_batch_mt_numa(const orc_params *p, int backend, int op, const double *bk_f, const uint32_t *ksk,
+                              const uint32_t *in0, const uint32_t *in1, size_t in_count, uint32_t *out, size_t count,
+                              int nthreads, const int *cpus, const int *node_of_thread, int nnodes) {
+    if (nthreads < 1 || nnodes < 1 || in_count < 1) return -1.0;
+    const size_t bk_doubles = (size_t)p->n * 2 * 2 * (size_t)p->l * (size_t)p->N;
+    const size_t ksk_words = (size_t)p->N * (size_t)p->ks_t * (((size_t)1 << p->ks_basebit) - 1) * ((size_t)p->n + 1);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    numa_job *jobs = (numa_job *)malloc(sizeof(numa_job) * (size_t)nthreads);
+    double **rep_bk = (double **)calloc((size_t)nnodes, sizeof(double *));
+    uint32_t **rep_ksk = (uint32_t **)calloc((size_t)nnodes, sizeof(uint32_t *));
+    int *seen = (int *)calloc((size_t)nnodes, sizeof(int));
+    int fail = 0;
+    pthread_barrier_t filled, ready;
+    pthread_barrier_init(&filled, NULL, (unsigned)nthreads);
+    pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1u);
+    struct timespec t0, t1;
+    for (int t = 0; t < nthreads; t++) {
+        int node = node_of_thread ? node_of_thread[t] : 0;
+        if (node < 0 || node >= nnodes) node = 0;
+        const int leader = !seen[node];
+        seen[node] = 1;
+        jobs[t] = (numa_job){p, backend, op, bk_f, bk_doubles, ksk, ksk_words, in0, in1, out, in_count,
+                             count * (size_t)t / (size_t)nthreads, count * (size_t)(t + 1) / (size_t)nthreads,
+                             cpus ? cpus[t] : -1, node, leader, rep_bk, rep_ksk, &filled, &ready, &fail};
+        pthread_create(&th[t], NULL, numa_worker, &jobs[t]);
+    }
+    pthread_barrier_wait(&ready);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    pthread_barrier_destroy(&filled);
+    pthread_barrier_destroy(&ready);
+    for (int k = 0; k < nnodes; k++) { free(rep_bk[k]); free(rep_ksk[k]); }
+    free(rep_bk); free(rep_ksk); free(seen); free(th); free(jobs);
+    if (fail) return -1.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* Sustained read bandwidth of the host, for the one sentence bench.py writes next to the all-core figure: every gate streams the whole
+ * 62 MB of key spectra and ~16 MB of key-switching rows, so the all-core CPU rate is bounded by (read bandwidth) / (78 MB per gate).
+ * Each of nthreads threads (pinned like the baseline's) sums a private buffer of `bytes` bytes, first-touched by itself, `passes` times.
+ * Returns bytes per second over all threads (from the moment every buffer is filled to the last thread's last pass); <= 0 on failure. */
+typedef struct { size_t bytes; int passes, cpu; pthread_barrier_t *ready; double sink; int fail; } bw_job;
+static void *bw_worker(void *arg) {
+    bw_job *j = (bw_job *)arg;
+    if (j->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(j->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    const size_t n = j->bytes / sizeof(double);
+    double *buf = (double *)malloc(n * sizeof(double));
+    if (!buf) j->fail = 1;
+    else for (size_t i = 0; i < n; i++) buf[i] = (double)(i & 1023);
+    pthread_barrier_wait(j->ready);
+    if (buf) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int pass = 0; pass < j->passes; pass++)
+            for (size_t i = 0; i + 4 <= n; i += 4) { a0 += buf[i]; a1 += buf[i + 1]; a2 += buf[i + 2]; a3 += buf[i + 3]; }
+        j->sink = a0 + a1 + a2 + a3;
+        free(buf);
+    }
+    return NULL;
+}
+double orc_stream_read_mt(size_t bytes_per_thread, int passes, int nthreads, const int *cpus) {
+    if (nthreads < 1 || passes < 1) return -1.0;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    bw_job *jobs = (bw_job *)malloc(sizeof(bw_job) * (size_t)nthreads);
+    pthread_barrier_t ready;
+    pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1u);
+    struct timespec t0, t1;
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (bw_job){bytes_per_thread, passes, cpus ? cpus[t] : -1, &ready, 0.0, 0};
+        pthread_create(&th[t], NULL, bw_worker, &jobs[t]);
+    }
+    pthread_barrier_wait(&ready);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int fail = 0;
+    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); fail |= jobs[t].fail; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    pthread_barrier_destroy(&ready);
+    free(th); free(jobs);
+    if (fail) return -1.0;
+    const double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    return secs > 0 ? (double)bytes_per_thread * passes * nthreads / secs : -1.0;
 }
 
 /* ================================================================= keys / encryption */

@@ -130,6 +130,15 @@ void orc_set_mt_hooks(void *(*new_fn)(int32_t), orc_fwd_hook fwd, orc_inv_hook i
 double orc_gate_batch_mt(const orc_params *p, int backend, int op, const double *bk_f, const uint32_t *bk_t,
                          const uint32_t *ksk, const uint32_t *in0, const uint32_t *in1, uint32_t *out,
                          size_t count, int nthreads);
+/* bench.py's all-core baseline: `count` gates over `in_count` distinct inputs (gate g takes input g % in_count, writes out[g]), threads
+ * optionally pinned (cpus[t] >= 0), keys replicated per memory node and first-touched by a thread of that node (node_of_thread[t] < nnodes).
+ * FP64-mirror / hook backends only (bk_f).  Returns the timed seconds, -1.0 on failure. */
+double orc_gate_batch_mt_numa(const orc_params *p, int backend, int op, const double *bk_f, const uint32_t *ksk,
+                              const uint32_t *in0, const uint32_t *in1, size_t in_count, uint32_t *out, size_t count,
+                              int nthreads, const int *cpus, const int *node_of_thread, int nnodes);
+
+/* sustained read bandwidth of the host in bytes per second (each thread sums a private, self-first-touched buffer `passes` times) */
+double orc_stream_read_mt(size_t bytes_per_thread, int passes, int nthreads, const int *cpus);
 
 /* ---------------------------------------------------------------- keys / encryption (own seeded RNG) */
 typedef struct { uint64_t s[4]; } orc_rng;

@@ -37,6 +37,15 @@
 #ifndef HALVES_B_LOW_MASK
 #define HALVES_B_LOW_MASK 0
 #endif
+// Round 4: buffer OWNERSHIP ping-pongs between the two halves (see "ping-pong" in the kernel): every trade needs ONE synchronisation instead of two.
+// -DHALVES_PINGPONG=0: round 3's write / sync / read / sync protocol (A/B builds).
+#ifndef HALVES_PINGPONG
+#define HALVES_PINGPONG 1
+#endif
+// with the ping-pong protocol: the next row's own twist products are computed between a row's arrival flag and the wait for the partner's
+#ifndef HALVES_EARLY_ROW
+#define HALVES_EARLY_ROW 1
+#endif
 #ifndef HALVES_SPLIT_MIN
 #define HALVES_SPLIT_MIN 3   // gates per workgroup from which the two halves trade the first stage's inputs instead of both computing all of them
 #endif
@@ -159,10 +168,25 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #else
 #define HALVES_SYNC() pair_sync(my_flag, partner_flag, ++sync_k)
 #endif
+#define HALVES_ARRIVE() pair_arrive(my_flag, ++sync_k)
+#define HALVES_WAIT() pair_wait(partner_flag, sync_k)
 #ifdef HALVES_ABL_NOSYNC       // timing ablation only (racy, wrong results)
 #undef HALVES_SYNC
 #define HALVES_SYNC() wave_lds_sync()
+#undef HALVES_ARRIVE
+#undef HALVES_WAIT
+#define HALVES_ARRIVE() wave_lds_sync()
+#define HALVES_WAIT() wave_lds_sync()
 #endif
+    constexpr bool PINGPONG = HALVES_PINGPONG != 0;
+    // Ping-pong ownership of the two exchange buffer pairs of a gate (round 4).  Round 3 traded a row as: write MY buffer, sync, read the PARTNER's, sync (the
+    // partner has read mine: it is free again) -- sixteen synchronisations per step, each a lock-step LDS round trip in which neither wave of the SIMD issues
+    // arithmetic.  Instead, after a trade each wave OWNS THE BUFFER IT HAS JUST READ: its next writes (the next row, or its sub-transform's wave-private
+    // exchanges) go there.  That buffer's previous writer is done with it (its writes precede its arrival flag), its reader is this wave itself (DS instructions
+    // of a wave execute in order), and nobody else touches it -- so the "buffer free" synchronisation disappears: ONE arrival / wait per trade, 8 per step.
+    // The accumulator updates at the end of a step are published by the arrivals that follow them (the other component's trade, the next step's first row).
+    double* wbuf = myx;    // the buffer pair this wave owns (writes next)
+    double* rbuf = otx;    // the partner's (read after its arrival)
 
     const int n = a.n;
     {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
@@ -270,8 +294,54 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 ure[m] = ((rotated_coef<LOGN>(poly, c0, r) - poly[c0]) + M) ^ M;
                 uim[m] = ((rotated_coef<LOGN>(poly, c1, r) - poly[c1]) + M) ^ M;
             }
-            double xr[R], xi[R];
             HV_STAMP(0);
+            if constexpr (PINGPONG) {
+            // one arrival / wait per row; the buffers swap owners after every row (see "ping-pong" above).  The next row's own twist products are computed
+            // between this row's arrival and the wait for the partner's (they need nothing from the partner; the row's sums then overwrite its own values,
+            // so the second register set costs nothing at the point where the register file is fullest: the third row).
+            double x[2][2][R];     // [row parity][re / im][point]
+            auto own_row2 = [&](int jj) {
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const double a0 = (double)decomp_digit(ure[m], BGBIT, jj), b0 = (double)decomp_digit(uim[m], BGBIT, jj);
+                    const double rc = a0 * tH[m].x, ic = b0 * tH[m].x, rs = a0 * tH[m].y, is = b0 * tH[m].y;
+                    x[jj & 1][0][m] = rc - is; x[jj & 1][1][m] = ic + rs;
+                }
+            };
+            own_row2(0);
+#pragma unroll
+            for (int jj = 0; jj < L; jj++) {
+                double* wb = (jj & 1) ? rbuf : wbuf;    // row 0: my buffer; row 1: the one I read in row 0; row 2: the one I read in row 1
+                double* rb = (jj & 1) ? wbuf : rbuf;
+                const double (&xr)[R] = x[jj & 1][0];
+                const double (&xi)[R] = x[jj & 1][1];
+#pragma unroll
+                for (int m = 0; m < R; m++) { lds_st(&wb[ln + 64 * m], xr[m]); lds_st(&wb[G::XSLOTS + ln + 64 * m], xi[m]); }
+                HALVES_ARRIVE();
+                if (HALVES_EARLY_ROW && jj + 1 < L) own_row2(jj + 1);
+                HALVES_WAIT();
+                if (H == 0) {                           // mine = x0, partner's = x1
+#pragma unroll
+                    for (int m = 0; m < R; m++) {
+                        yr[jj][m] = xr[m] + lds_ld(&rb[ln + 64 * m]);
+                        yi[jj][m] = xi[m] + lds_ld(&rb[G::XSLOTS + ln + 64 * m]);
+                    }
+                } else {                                // mine = x1, partner's = x0
+#pragma unroll
+                    for (int m = 0; m < R; m++) {
+                        const cplx w1 = tw_st1[m * 64 + ln];
+                        const double dr = lds_ld(&rb[ln + 64 * m]) - xr[m], di = lds_ld(&rb[G::XSLOTS + ln + 64 * m]) - xi[m];
+                        double p = dr * w1.x, q = di * w1.y;
+                        yr[jj][m] = p - q;
+                        p = dr * w1.y; q = di * w1.x;
+                        yi[jj][m] = p + q;
+                    }
+                }
+                if (!HALVES_EARLY_ROW && jj + 1 < L) own_row2(jj + 1);
+            }
+            { double* t = wbuf; wbuf = rbuf; rbuf = t; }        // three rows: I now own the buffer I read last (row 2 read rbuf)
+            } else {
+            double xr[R], xi[R];
             auto own_row = [&](int jj) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
@@ -308,6 +378,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 if (jj + 1 < L) own_row(jj + 1);
                 HALVES_SYNC();                          // both waves have read: the buffers are free (next row / the sub-transforms' exchanges)
             }
+            }
             } else {
 #pragma unroll
             for (int m = 0; m < R; m++) {
@@ -343,13 +414,13 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 }
 #ifndef HALVES_NO_POINT_BARRIER
                 __builtin_amdgcn_sched_barrier(0);      // one point at a time: keeps the gather of later points from being hoisted
-            }
-            }
 #endif
+            }
+            }
             HV_STAMP(1);
             prio_point(1);
             // the 512-point sub-transforms of the three rows side by side
-            fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, myx, myx + G::XSLOTS, ln);
+            fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
             prio_point(2);
 #ifndef HALVES_FETCH_LATE
             fetch(bA, i, h * 2 * L);                    // (row 0, comp 0) of this polynomial: in flight under the last pass
@@ -390,9 +461,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 w3.load(twi_small + G::TW_P3, 1);
                 P3<R, G::NLOW, G::LOW - 1, BOOT_TRIV>::template inv<false>(re, im, w3.w);
                 w2.load(twi_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
-                exchange<10, 3, 2, true>(re, im, myx, lane);
+                exchange<10, 3, 2, true>(re, im, wbuf, lane);
                 P12<R, G::LR - 1>::inv(re, im, w2.w);
-                exchange<10, 2, 1, true>(re, im, myx, lane);
+                exchange<10, 2, 1, true>(re, im, wbuf, lane);
                 if constexpr (IST_EARLY) {
                     if (H == 1) {   // requested under the last pass
 #pragma unroll
@@ -414,31 +485,22 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 }
             }
 #pragma unroll
-#ifdef HALVES_CROSS_PAIRED
-            for (int m = 0; m < R; m++) { myx[lane + 64 * m] = re[m]; myx[G::XSLOTS + lane + 64 * m] = im[m]; }
-#else
-            for (int m = 0; m < R; m++) { lds_st(&myx[lane + 64 * m], re[m]); lds_st(&myx[G::XSLOTS + lane + 64 * m], im[m]); }
-#endif
-            Tw<R> wt;      // untwist (times 2/N) of this half's points, from global memory: in flight across the barrier
+            for (int m = 0; m < R; m++) { lds_st(&wbuf[lane + 64 * m], re[m]); lds_st(&wbuf[G::XSLOTS + lane + 64 * m], im[m]); }
+            if constexpr (PINGPONG) HALVES_ARRIVE();
+            Tw<R> wt;      // untwist (times 2/N) of this half's points, from global memory: in flight across the synchronisation
 #pragma unroll
             for (int m = 0; m < R; m++) wt.w[m] = guntw0[(H * 8 + m) * 64 + lane];
-            HALVES_SYNC();
+            if constexpr (PINGPONG) HALVES_WAIT(); else HALVES_SYNC();
             {
                 uint32_t* poly = accbuf + comp * N;
                 // A: x0 + t, B: x0 - t.  Branch on the half outside the loop: a select would compute both (4 more FP64 instructions per point)
-#ifdef HALVES_CROSS_PAIRED
-#define HALVES_OTX(k) otx[k]
-#else
-#define HALVES_OTX(k) lds_ld(&otx[k])
-#endif
                 if (H) {
 #pragma unroll
-                    for (int m = 0; m < R; m++) { re[m] = HALVES_OTX(lane + 64 * m) - re[m]; im[m] = HALVES_OTX(G::XSLOTS + lane + 64 * m) - im[m]; }
+                    for (int m = 0; m < R; m++) { re[m] = lds_ld(&rbuf[lane + 64 * m]) - re[m]; im[m] = lds_ld(&rbuf[G::XSLOTS + lane + 64 * m]) - im[m]; }
                 } else {
 #pragma unroll
-                    for (int m = 0; m < R; m++) { re[m] = re[m] + HALVES_OTX(lane + 64 * m); im[m] = im[m] + HALVES_OTX(G::XSLOTS + lane + 64 * m); }
+                    for (int m = 0; m < R; m++) { re[m] = re[m] + lds_ld(&rbuf[lane + 64 * m]); im[m] = im[m] + lds_ld(&rbuf[G::XSLOTS + lane + 64 * m]); }
                 }
-#undef HALVES_OTX
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     const double vr = re[m], vi = im[m];
@@ -449,12 +511,19 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                     poly[c + P] += trunc_to_torus(ic + rs);
                 }
             }
-            HALVES_SYNC();     // the partner has read my buffer; both halves of the accumulator are written
+            if constexpr (PINGPONG) {
+                // I own the buffer I have just read; my accumulator words are published by my next arrival (the other component's trade / the next
+                // step's first row), which the partner waits for before it gathers them
+                double* t = wbuf; wbuf = rbuf; rbuf = t;
+            } else {
+                HALVES_SYNC();     // the partner has read my buffer; both halves of the accumulator are written
+            }
             HV_STAMP(5);
             prio_point(6);
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (PINGPONG) __syncthreads();      // the last accumulator update has no arrival behind it: both halves' words must be visible below
 #ifdef RTFHE_WG_STAMPS
     if (a.dbg && blockIdx.x == 0 && lane0 == 0)
         for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];

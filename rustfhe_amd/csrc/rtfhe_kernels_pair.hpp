@@ -79,6 +79,19 @@ __device__ __forceinline__ void pair_sync(unsigned my_flag_addr, unsigned partne
     } while ((int)(v - k) < 0);
 }
 
+// The two halves of pair_sync as separate calls (split phase): a wave publishes its arrival, does work that needs nothing from its partner, and only
+// then waits -- the flag's LDS round trip lands under that work instead of idling the wave.
+__device__ __forceinline__ void pair_arrive(unsigned my_flag_addr, unsigned k) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(my_flag_addr), "v"(k) : "memory");
+}
+__device__ __forceinline__ void pair_wait(unsigned partner_flag_addr, unsigned k) {
+    unsigned v;
+    do {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(partner_flag_addr) : "memory");
+        v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    } while ((int)(v - k) < 0);
+}
+
 template <int R>
 __device__ __forceinline__ void mac_row_first(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
 #pragma unroll
@@ -320,6 +333,22 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
             for (int m = 0; m < R; m++) { sre[m] = 0.0; sim[m] = 0.0; }
         };
+#ifdef PAIR_HAND_B64      // A/B: the hand-offs as 8-byte accesses, never paired (lds_st / lds_ld), real parts then imaginary parts: [2][R][64] doubles
+        auto put = [&](cplx* h) {
+            double* d = reinterpret_cast<double*>(h - lane) + lane;
+#pragma unroll
+            for (int m = 0; m < R; m++) lds_st(&d[m * 64], sre[m]);
+#pragma unroll
+            for (int m = 0; m < R; m++) lds_st(&d[R * 64 + m * 64], sim[m]);
+        };
+        auto get = [&](const cplx* h) {
+            const double* d = reinterpret_cast<const double*>(h - lane) + lane;
+#pragma unroll
+            for (int m = 0; m < R; m++) sre[m] = lds_ld(&d[m * 64]);
+#pragma unroll
+            for (int m = 0; m < R; m++) sim[m] = lds_ld(&d[R * 64 + m * 64]);
+        };
+#else
         auto put = [&](cplx* h) {
 #pragma unroll
             for (int m = 0; m < R; m++) h[m * 64] = make_double2(sre[m], sim[m]);
@@ -328,6 +357,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
             for (int m = 0; m < R; m++) { const cplx v = h[m * 64]; sre[m] = v.x; sim[m] = v.y; }
         };
+#endif
 
         // slot P (side 0): component 0 over rows 0..2 from +0.0
         if (side == 0) {

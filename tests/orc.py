@@ -100,6 +100,8 @@ def lib():
         "orc_gate": (None, [PP, vp, C.c_int, f64p, u32p, u32p, u32p, u32p, u32p]),
         "orc_mux": (None, [PP, vp, f64p, u32p, u32p, u32p, u32p, u32p, u32p]),
         "orc_gate_batch_mt": (C.c_double, [PP, C.c_int, C.c_int, f64p, u32p, u32p, u32p, u32p, u32p, C.c_size_t, C.c_int]),
+        "orc_gate_batch_mt_numa": (C.c_double, [PP, C.c_int, C.c_int, f64p, u32p, u32p, u32p, C.c_size_t, u32p, C.c_size_t, C.c_int, i32p, i32p, C.c_int]),
+        "orc_stream_read_mt": (C.c_double, [C.c_size_t, C.c_int, C.c_int, i32p]),
         "orc_set_mt_hooks": (None, [vp, vp, vp]),
         "orc_rng_seed": (None, [C.POINTER(Rng), C.c_uint64]),
         "orc_rng_next": (C.c_uint64, [C.POINTER(Rng)]),
@@ -369,6 +371,92 @@ def gate_batch_mt(params, op, bk_f, bk_t, ksk, in0, in1, nthreads, backend=BACKE
                                    _p(ksk, C.c_uint32), _p(in0, C.c_uint32), _p(in1, C.c_uint32),
                                    _p(out, C.c_uint32), in0.shape[0], nthreads)
     return out, secs
+
+
+def host_topology():
+    """What the all-core baseline needs to know about the host: the hardware threads this process may run on, which physical core and
+    memory node each belongs to, and the CPU-time quota of the enclosing cgroup (a container may see every CPU of the machine and still be
+    entitled to a few cores' worth of time).  Plain reads of /proc and /sys; anything unreadable degrades to 'one node, no quota'."""
+    threads = sorted(os.sched_getaffinity(0))
+    core_of, node_of = {}, {}
+    try:
+        cur = {}
+        with open("/proc/cpuinfo") as f:
+            for ln in f.read().split("\n") + [""]:
+                if ":" in ln:
+                    k, v = ln.split(":", 1)
+                    cur[k.strip()] = v.strip()
+                elif cur:
+                    cpu = int(cur.get("processor", -1))
+                    core_of[cpu] = (cur.get("physical id", "0"), cur.get("core id", str(cpu)))
+                    cur = {}
+    except OSError:
+        pass
+    try:
+        base = "/sys/devices/system/node"
+        for d in sorted(os.listdir(base)):
+            if d.startswith("node") and d[4:].isdigit():
+                with open(os.path.join(base, d, "cpulist")) as f:
+                    for part in f.read().strip().split(","):
+                        if part:
+                            lo, _, hi = part.partition("-")
+                            for cpu in range(int(lo), int(hi or lo) + 1):
+                                node_of[cpu] = int(d[4:])
+    except (OSError, ValueError):
+        pass
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            with open(path) as f:
+                t = f.read().strip()
+            if parse:
+                quota = parse(t)
+            elif int(t) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    quota = int(t) / float(f2.read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    first_of_core = {}
+    for cpu in threads:
+        first_of_core.setdefault(core_of.get(cpu, ("0", str(cpu))), cpu)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    core_ids = {k: i for i, k in enumerate(sorted(first_of_core))}
+    return {"hw_threads": threads, "one_thread_per_core": sorted(first_of_core.values()), "node_of": {c: node_of.get(c, 0) for c in threads},
+            "core_of": {c: core_ids[core_of.get(c, ("0", str(c)))] for c in threads},
+            "nodes": sorted(set(node_of.get(c, 0) for c in threads)), "cgroup_cpu_quota": quota, "cpu_model": model}
+
+
+def gate_batch_mt_numa(params, op, bk_f, ksk, in0, in1, count, cpus, node_of, backend=BACKEND_MIRROR, pin=True):
+    """`count` gates over the inputs in0 / in1 (gate g takes input g % len(in0)) on len(cpus) threads, thread t pinned to cpus[t] (pin) and
+    reading the key replica of memory node node_of[cpus[t]] (first-touched by a thread of that node).  Returns (out[count], seconds)."""
+    in0 = np.ascontiguousarray(in0, np.uint32)
+    in1 = in0 if in1 is None else np.ascontiguousarray(in1, np.uint32)
+    out = np.empty((count, in0.shape[1]), np.uint32)
+    nodes = sorted(set(node_of[c] for c in cpus))
+    cpu_arr = np.array([c if pin else -1 for c in cpus], np.int32)
+    node_arr = np.array([nodes.index(node_of[c]) for c in cpus], np.int32)
+    secs = lib().orc_gate_batch_mt_numa(C.byref(params), backend, op, _p(bk_f, C.c_double), _p(ksk, C.c_uint32), _p(in0, C.c_uint32),
+                                        _p(in1, C.c_uint32), in0.shape[0], _p(out, C.c_uint32), count, len(cpus),
+                                        _p(cpu_arr, C.c_int32), _p(node_arr, C.c_int32), len(nodes))
+    if secs < 0:
+        raise MemoryError("orc_gate_batch_mt_numa: key replica allocation failed")
+    return out, secs
+
+
+def stream_read_bandwidth(cpus, bytes_per_thread=256 << 20, passes=3, pin=True):
+    """bytes per second all len(cpus) threads read together from private buffers far larger than their caches"""
+    arr = np.array([c if pin else -1 for c in cpus], np.int32)
+    return lib().orc_stream_read_mt(bytes_per_thread, passes, len(cpus), _p(arr, C.c_int32))
 
 
 _mt_ref = None

@@ -134,3 +134,111 @@ def test_ntt_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
     assert m, "k_bootstrap_ntt_pair not found in the device assembly"
     f64 = len(re.findall(r"^\s*v_\w+_f64", m.group(2), re.M))
     assert f64 == bench.ntt_dp_wave_instr_per_cmux(1024, 3)["loop_static"], f64
+
+
+# ---- round 4: the headline must survive the death of a side leg -------------------------------------------------
+FAKE_INNER = r'''
+import json, os, sys
+assert os.environ.get("RTFHE_BENCH_INNER") == "1"
+print("RCCL banner or other stray text")
+print(json.dumps({"metric": "m", "value": 1.0, "provisional": ["cpu_baseline", "secondary"]}), flush=True)
+print(json.dumps({"metric": "m", "value": 1.0, "cpu_baseline": {"value": 2}, "provisional": ["secondary"]}), flush=True)
+MODE
+'''
+
+
+@pytest.mark.parametrize("mode, crash", [("os.abort()", True), ("print(json.dumps({'metric': 'm', 'value': 1.0, 'cpu_baseline': {'value': 2}, 'secondary': {}}), flush=True)", False)])
+def test_supervisor_prints_the_last_complete_line_even_if_the_measuring_process_dies(tmp_path, capfd, mode, crash):
+    import bench
+    child = tmp_path / "inner.py"
+    child.write_text(FAKE_INNER.replace("MODE", mode))
+    rc = bench.supervise([sys.executable, str(child)])
+    out = capfd.readouterr().out.strip().split("\n")
+    assert rc == 0 and len(out) == 1, out                       # ONE line on stdout, exit code 0
+    line = json.loads(out[0])
+    assert line["value"] == 1.0 and line["cpu_baseline"] == {"value": 2} and "provisional" not in line
+    if crash:
+        assert line["side_leg_crash"]["signal"] == "SIGABRT" and line["side_leg_crash"]["legs_not_completed"] == ["secondary"]
+    else:
+        assert "side_leg_crash" not in line and line["secondary"] == {}
+
+
+def test_supervisor_without_any_line_reports_the_exit_code(tmp_path, capfd):
+    import bench
+    child = tmp_path / "inner.py"
+    child.write_text("import sys\nsys.exit(7)\n")
+    assert bench.supervise([sys.executable, str(child)]) == 7
+    assert capfd.readouterr().out == ""
+
+
+@pytest.fixture(scope="module")
+def baseline_inputs():
+    """keys, 8 NAND inputs and the oracle's outputs for them (standing in for the GPU's: the child only compares)"""
+    import numpy as np
+    import ctypes as C
+    import rustfhe_amd as R
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    P = R.Params()
+    key0, key1, bk, ksk = R.keygen(P, 424242)
+    b0 = np.array([0, 0, 1, 1, 1, 0, 1, 0], np.uint8)
+    b1 = np.array([0, 1, 0, 1, 1, 1, 0, 0], np.uint8)
+    in0, in1 = R.encrypt_bits(P, key0, b0, 1), R.encrypt_bits(P, key0, b1, 2)
+    p = orc.Params()
+    pl = orc.Plan(p.N)
+    bk_f = np.empty(bk.size, np.float64)
+    orc.lib().orc_trgsw_to_fft(pl.h, bk.ctypes.data_as(C.POINTER(C.c_uint32)), bk_f.ctypes.data_as(C.POINTER(C.c_double)), bk.size // p.N)
+    exp, _ = orc.gate_batch_mt(p, orc.NAND, bk_f, None, ksk, in0, in1, 4)
+    return np, P, bk, ksk, in0, in1, exp
+
+
+def test_cpu_baseline_child_measures_tiled_batches_on_pinned_threads(baseline_inputs, monkeypatch):
+    import bench
+    np, P, bk, ksk, in0, in1, exp = baseline_inputs
+    monkeypatch.setenv("RTFHE_BENCH_CPU_TARGET_S", "0.2")
+    child = bench.CpuBaselineChild(np, P, bk, ksk, in0, in1, 6)
+    res = child.collect(exp, timeout=600)
+    assert "error" not in res, res
+    assert res["matches_gpu_bit_exact"] is True and res["value"] > 0 and res["unit"] == "gates/s"
+    for leg in (res, res.get("port", res)):
+        for run in leg["runs"]:
+            assert run["gates_per_thread"] >= 6 and run["gates"] == run["gates_per_thread"] * run["threads_used"] and run["matches_gpu_bit_exact"]
+        assert 0 < leg["scaling_efficiency"] <= 1.5
+    assert res["host"]["physical_cores"] >= 1 and res["memory"]["stream_read_GBps"] > 0
+    assert not os.path.exists(child.dir)                        # the scratch directory is gone
+
+
+def test_cpu_baseline_child_abort_is_an_error_entry_not_a_lost_line(baseline_inputs, monkeypatch):
+    import bench
+    np, P, bk, ksk, in0, in1, exp = baseline_inputs
+    monkeypatch.setenv("RTFHE_BENCH_TEST_ABORT", "cpu_child")
+    res = bench.CpuBaselineChild(np, P, bk, ksk, in0, in1, 6).collect(exp, timeout=600)
+    assert res["rc"] == -6 and "SIGABRT" in res["error"]
+
+
+def test_a_wrong_gpu_output_is_reported_as_a_mismatch(baseline_inputs, monkeypatch):
+    import bench
+    np, P, bk, ksk, in0, in1, exp = baseline_inputs
+    monkeypatch.setenv("RTFHE_BENCH_CPU_TARGET_S", "0.05")
+    bad = exp.copy()
+    bad[3, 17] ^= 1
+    res = bench.CpuBaselineChild(np, P, bk, ksk, in0, in1, 1).collect(bad, timeout=600)
+    assert res["matches_gpu_bit_exact"] is False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["cpu_child", "secondary"])
+def test_bench_headline_survives_an_abort_in_a_side_leg(where):
+    env = dict(os.environ, RTFHE_BENCH_TEST_ABORT=where)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-gates-per-thread", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["outputs_decrypt_correctly"] and line["roofline"]["frac"] > 0
+    if where == "cpu_child":
+        assert "SIGABRT" in line["cpu_baseline"]["error"] and "secondary" in line
+    else:
+        assert line["side_leg_crash"]["signal"] == "SIGABRT" and line["side_leg_crash"]["legs_not_completed"] == ["secondary"]
+        assert "value" in line["cpu_baseline"] or "error" in line["cpu_baseline"]
