@@ -15,6 +15,7 @@ pub struct rtfhe_params {
 }
 pub enum rtfhe_ctx {}
 pub enum rtfhe_circuit {}
+pub enum rtfhe_fft_plan {}
 
 pub const RTFHE_NAND: c_int = 0;
 pub const RTFHE_AND: c_int = 1;
@@ -50,6 +51,9 @@ extern "C" {
     pub fn rtfhe_get_backend(ctx: *const rtfhe_ctx) -> c_int;
     pub fn rtfhe_get_twiddles(ctx: *const rtfhe_ctx, ifft_table: *mut f64, fft_table: *mut f64) -> c_int;
     pub fn rtfhe_set_twiddles(ctx: *mut rtfhe_ctx, ifft_table: *const f64, fft_table: *const f64) -> c_int;
+    pub fn rtfhe_ctx_params(ctx: *const rtfhe_ctx, p: *mut rtfhe_params) -> c_int;
+    pub fn rtfhe_twiddles_load(ctx: *mut rtfhe_ctx, path: *const c_char, entries_changed: *mut i32) -> c_int;
+    pub fn rtfhe_twiddles_write(ctx: *const rtfhe_ctx, path: *const c_char) -> c_int;
 
     pub fn rtfhe_load_bk_torus(ctx: *mut rtfhe_ctx, bk: *const u32) -> c_int;
     pub fn rtfhe_load_bk_fft(ctx: *mut rtfhe_ctx, bk_f: *const f64) -> c_int;
@@ -83,6 +87,18 @@ extern "C" {
     pub fn rtfhe_ifft_f64_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut f64, count: usize) -> c_int;
     pub fn rtfhe_fft_f64_batch(ctx: *mut rtfhe_ctx, src: *const f64, res: *mut f64, count: usize) -> c_int;
     pub fn rtfhe_poly_mul_batch(ctx: *mut rtfhe_ctx, a: *const u32, b: *const u32, res: *mut u32, count: usize) -> c_int;
+
+    // the reference's transforms at any power of two 16 <= N <= 2048 (FFT_Processor_Spqlios(N); Spqlios::new takes them all)
+    pub fn rtfhe_fft_plan_create(n: i32, device_id: c_int, out: *mut *mut rtfhe_fft_plan) -> c_int;
+    pub fn rtfhe_fft_plan_destroy(plan: *mut rtfhe_fft_plan);
+    pub fn rtfhe_fft_plan_degree(plan: *const rtfhe_fft_plan) -> i32;
+    pub fn rtfhe_fft_plan_get_twiddles(plan: *const rtfhe_fft_plan, ifft_table: *mut f64, fft_table: *mut f64) -> c_int;
+    pub fn rtfhe_fft_plan_set_twiddles(plan: *mut rtfhe_fft_plan, ifft_table: *const f64, fft_table: *const f64) -> c_int;
+    pub fn rtfhe_fft_plan_ifft_i32(plan: *mut rtfhe_fft_plan, src: *const i32, res: *mut f64, count: usize) -> c_int;
+    pub fn rtfhe_fft_plan_ifft_f64(plan: *mut rtfhe_fft_plan, src: *const f64, res: *mut f64, count: usize) -> c_int;
+    pub fn rtfhe_fft_plan_fft_u32(plan: *mut rtfhe_fft_plan, src: *const f64, res: *mut u32, count: usize) -> c_int;
+    pub fn rtfhe_fft_plan_fft_f64(plan: *mut rtfhe_fft_plan, src: *const f64, res: *mut f64, count: usize) -> c_int;
+    pub fn rtfhe_fft_plan_poly_mul(plan: *mut rtfhe_fft_plan, a: *const u32, b: *const u32, res: *mut u32, count: usize) -> c_int;
 
     // production: randomness from the OS CSPRNG (like the reference's thread_rng)
     pub fn rtfhe_keygen(p: *const rtfhe_params, key0: *mut i32, key1: *mut i32, bk: *mut u32, ksk: *mut u32) -> c_int;

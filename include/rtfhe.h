@@ -124,6 +124,16 @@ int rtfhe_get_backend(const rtfhe_ctx *ctx);
 /* twiddle tables in the reference's memory layout (2N doubles each direction; blocks 4 cos | 4 sin) */
 int rtfhe_get_twiddles(const rtfhe_ctx *ctx, double *ifft_table, double *fft_table);
 int rtfhe_set_twiddles(rtfhe_ctx *ctx, const double *ifft_table, const double *fft_table);
+int rtfhe_ctx_params(const rtfhe_ctx *ctx, rtfhe_params *p);     /* the parameter set the context was created with */
+/* The tables are DATA: the reference builds them with libm's cos / sin of a double-rounded angle (accurate_cos / accurate_sin,
+ * utils/src/spqlios/spqlios-fft-impl.cpp:99-113), two hosts' libms may differ by an ulp in a few entries, and one differing entry changes
+ * torus words.  rtfhe_ctx_create builds them with THIS host's libm -- what a reference built on this host would hold.  To
+ * reproduce another build's bits, ship its tables as a file ("RTFHETW1" | i32 N | i32 0 | f64 ifft_table[2N] | f64 fft_table[2N] | u64 fnv1a):
+ * rtfhe_twiddles_load installs the file's tables only if they differ from the context's (*entries_changed = differing entries, may be
+ * NULL; a key loaded in torus form is re-transformed); rtfhe_twiddles_write saves the context's.  rustfhe_amd/assets/twiddles_N*.bin are
+ * the tables of the reference build the golden vectors under tests/golden/ were made with. */
+int rtfhe_twiddles_load(rtfhe_ctx *ctx, const char *path, int32_t *entries_changed);
+int rtfhe_twiddles_write(const rtfhe_ctx *ctx, const char *path);
 
 /* ---- keys ---- */
 int rtfhe_load_bk_torus(rtfhe_ctx *ctx, const uint32_t *bk /* [n][2][2l][N] */);
@@ -167,8 +177,12 @@ int rtfhe_sync(rtfhe_ctx *ctx, void *stream);
  * `stream`); end returns total milliseconds and the number of kernel launches */
 int rtfhe_timer_begin(rtfhe_ctx *ctx, void *stream);
 int rtfhe_timer_end(rtfhe_ctx *ctx, void *stream, double *ms, int64_t *launches);
-/* the same, and of the total the device time spent in the batch key switches of the split path (plain batches of >= 1024 gates at
- * N = 1024 run blind rotation + sample extract and the key switch of the whole batch as two launches; 0 when all were fused) */
+/* the same, and of the total the device time spent in the batch key switches of the split path.  Every batch of at least
+ * RTFHE_KS_MM_MIN gates (environment, default 1: every batch -- any size, netlist waves, N = 1024 and 2048, both backends) runs as two
+ * launches: blind rotation + sample extract (which also zeroes the gates' output rows), then the key switch of the whole batch as one
+ * exact i8 contraction (k_key_switch_mm).  RTFHE_KS_MM_MIN=0 keeps the key switch fused into the bootstrap kernel; so does a batch
+ * enqueued inside a caller's own stream capture (the split path's scratch buffer belongs to the stream, not to the caller's graph) --
+ * key_switch_ms is 0 when all were fused, and the launches of an rtfhe_circuit are never bracketed. */
 int rtfhe_timer_end_detail(rtfhe_ctx *ctx, void *stream, double *ms, double *key_switch_ms, int64_t *launches);
 
 /* ---- stage-level entry points (parity tests; same kernels' building blocks) ---- */
@@ -184,6 +198,25 @@ int rtfhe_fft_u32_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, uint
 int rtfhe_ifft_f64_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, double *res /* [count][N] */, size_t count);
 int rtfhe_fft_f64_batch(rtfhe_ctx *ctx, const double *src /* [count][N] */, double *res /* [count][N], no truncation */, size_t count);
 int rtfhe_poly_mul_batch(rtfhe_ctx *ctx, const uint32_t *a, const uint32_t *b, uint32_t *res /* [count][N] each */, size_t count);
+
+/* ---- the reference's transforms at ANY power of two 16 <= N <= 2048 ----
+ * The reference's FFT FFI takes every such N (Spqlios::new, utils/src/spqlios.rs:40-50; FFT_Processor_Spqlios, fft_processor_spqlios.cpp:7-14)
+ * and its own unit test runs at N = 16 (spqlios.rs:243-276); a context exists for the gate path's N = 1024 / 2048 only.  A plan holds
+ * the twiddle tables of one N on one device and runs the same butterfly networks (ifft_model / fft_model, spqlios-fft-impl.cpp:469-641 /
+ * 204-397) on the GPU, one workgroup per polynomial: the same bytes as the reference for every N, with no claim of speed.  Not
+ * thread-safe (one plan per host thread, as the reference's thread_local FFT_MAP, math.rs:349-351); host pointers in and out; errors
+ * through rtfhe_last_error(NULL).  The Spqlios_* symbols of rtfhe_spqlios.h use a plan for every N other than 1024 / 2048. */
+typedef struct rtfhe_fft_plan rtfhe_fft_plan;
+int rtfhe_fft_plan_create(int32_t N, int device_id, rtfhe_fft_plan **out);      /* FFT_Processor_Spqlios(N), fft_processor_spqlios.cpp:7-14 */
+void rtfhe_fft_plan_destroy(rtfhe_fft_plan *plan);
+int32_t rtfhe_fft_plan_degree(const rtfhe_fft_plan *plan);
+int rtfhe_fft_plan_get_twiddles(const rtfhe_fft_plan *plan, double *ifft_table /* [2N] */, double *fft_table /* [2N] */);   /* reference layout */
+int rtfhe_fft_plan_set_twiddles(rtfhe_fft_plan *plan, const double *ifft_table, const double *fft_table);
+int rtfhe_fft_plan_ifft_i32(rtfhe_fft_plan *plan, const int32_t *src, double *res, size_t count);    /* execute_reverse_int / _torus32 */
+int rtfhe_fft_plan_ifft_f64(rtfhe_fft_plan *plan, const double *src, double *res, size_t count);     /* execute_reverse */
+int rtfhe_fft_plan_fft_u32(rtfhe_fft_plan *plan, const double *src, uint32_t *res, size_t count);    /* execute_direct_torus32 */
+int rtfhe_fft_plan_fft_f64(rtfhe_fft_plan *plan, const double *src, double *res, size_t count);      /* execute_direct */
+int rtfhe_fft_plan_poly_mul(rtfhe_fft_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *res, size_t count);   /* spqlios-wrapper.cpp:38-53 */
 
 /* ---- key generation / encryption (host side) ----
  * Production entry points draw every key bit, mask and noise sample from the OS CSPRNG (getrandom(2), expanded with ChaCha20),

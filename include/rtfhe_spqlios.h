@@ -11,10 +11,13 @@
  *   - res / src are caller-allocated arrays of N elements (FrrSeries: Re[0..N/2) then Im[0..N/2), spqlios.rs:147,205-208);
  *   - no error returns: the reference's require() aborts (spqlios-fft-impl.cpp:92-97), and so does a failed call here, after
  *     printing the engine's error to stderr.
- * Differences, all in the direction of safety: Spqlios_new returns NULL for an N other than 1024 / 2048 or when no MI355X is
- * usable (the reference accepts any power of two >= 16); Spqlios_destructor also releases the handle's memory (the reference
- * runs the C++ destructor only and leaks the object, spqlios-wrapper.cpp:14-16 -- its Rust side never touches the pointer
- * again, spqlios.rs:139-145).  Device: RTFHE_SPQLIOS_DEVICE (default 0).
+ * Sizes: every power of two 16 <= N <= 2048, as the reference (Spqlios::new asserts N >= 16 and a power of two, spqlios.rs:40-50; its
+ * unit test runs at 16, :243-276).  N = 1024 / 2048 run on the gate path's wave-resident transforms, the others on rtfhe_fft_plan
+ * (rtfhe.h): one workgroup per polynomial, the same butterfly networks, the same bytes.
+ * Differences, all in the direction of safety: Spqlios_new returns NULL for any other N (the reference aborts in require()) or when no
+ * MI355X is usable; Spqlios_destructor also releases the handle's memory (the reference runs the C++ destructor only and leaks the
+ * object, spqlios-wrapper.cpp:14-16 -- its Rust side never touches the pointer again, spqlios.rs:139-145).  Device:
+ * RTFHE_SPQLIOS_DEVICE (default 0).
  */
 #ifndef RTFHE_SPQLIOS_H
 #define RTFHE_SPQLIOS_H

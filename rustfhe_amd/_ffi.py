@@ -49,6 +49,9 @@ _SIGNATURES = {
     "rtfhe_get_backend": (C.c_int, [C.c_void_p]),
     "rtfhe_get_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_set_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_ctx_params": (C.c_int, [C.c_void_p, "PP"]),
+    "rtfhe_twiddles_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
+    "rtfhe_twiddles_write": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rtfhe_load_bk_torus": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_load_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_export_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -75,6 +78,16 @@ _SIGNATURES = {
     "rtfhe_ifft_f64_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_fft_f64_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_poly_mul_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_plan_create": (C.c_int, [C.c_int32, C.c_int, C.POINTER(C.c_void_p)]),
+    "rtfhe_fft_plan_destroy": (None, [C.c_void_p]),
+    "rtfhe_fft_plan_degree": (C.c_int32, [C.c_void_p]),
+    "rtfhe_fft_plan_get_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_fft_plan_set_twiddles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtfhe_fft_plan_ifft_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_plan_ifft_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_plan_fft_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_plan_fft_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtfhe_fft_plan_poly_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_keygen": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_keygen_with_keys": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtfhe_tlwe_encrypt_bits": (C.c_int, ["PP", C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -288,12 +288,30 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #pragma unroll
             for (int m = 0; m < R; m++) tH[m] = gtwist[(8 * H + m) * 64];
             uint32_t ure[R], uim[R];
+#ifdef HALVES_GATHER2     // A/B: the rotated gather on byte offsets -- one add per coefficient from a per-polynomial base, mask, sign by xor / subtract
+            {
+                const int e0 = (ln + 512 * H - r) * 4;                   // 4 (c - r) for m = 0; the coefficients of a lane are 256 m and 4096 bytes apart
+                const unsigned char* pb = reinterpret_cast<const unsigned char*>(poly);
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const int c0 = ln + 64 * m + 512 * H, c1 = c0 + 1024;
+                    const int t0 = e0 + 256 * m, t1 = t0 + 4096;
+                    const uint32_t v0 = *reinterpret_cast<const uint32_t*>(pb + (t0 & (4 * N - 4)));
+                    const uint32_t v1 = *reinterpret_cast<const uint32_t*>(pb + (t1 & (4 * N - 4)));
+                    const uint32_t s0 = (uint32_t)((int32_t)((uint32_t)t0 << (31 - LOGN - 2)) >> 31);     // all ones iff bit LOGN of (c - r) is set
+                    const uint32_t s1 = (uint32_t)((int32_t)((uint32_t)t1 << (31 - LOGN - 2)) >> 31);
+                    ure[m] = ((((v0 ^ s0) - s0) - poly[c0]) + M) ^ M;
+                    uim[m] = ((((v1 ^ s1) - s1) - poly[c1]) + M) ^ M;
+                }
+            }
+#else
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 const int c0 = ln + 64 * m + 512 * H, c1 = c0 + 1024;
                 ure[m] = ((rotated_coef<LOGN>(poly, c0, r) - poly[c0]) + M) ^ M;
                 uim[m] = ((rotated_coef<LOGN>(poly, c1, r) - poly[c1]) + M) ^ M;
             }
+#endif
             HV_STAMP(0);
             if constexpr (PINGPONG) {
             // one arrival / wait per row; the buffers swap owners after every row (see "ping-pong" above).  The next row's own twist products are computed

@@ -73,7 +73,7 @@ __device__ __forceinline__ void ntt_halves_load_tables(double* lds, const double
 // addresses, sync_k the running count) instead of the workgroup barrier.
 template <int L, int BGBIT, bool CMUX, bool PAIRSYNC = false>
 __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const __amdgpu_buffer_rsrc_t bk_rsrc, int bk_off,
-                                                const NttHalvesTables& t, double* __restrict__ myx, const double* __restrict__ otx,
+                                                const NttHalvesTables& t, double* myx, const double* otx,      /* the partner writes otx: no restrict */
                                                 int lane0, int H, unsigned my_flag = 0, unsigned partner_flag = 0, unsigned* sync_k = nullptr) {
     auto halves_sync = [&]() {
         if constexpr (PAIRSYNC) pair_sync(my_flag, partner_flag, ++*sync_k);
@@ -152,16 +152,16 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
             ntt::inverse_rev(x, t.mir, myx, lane);
             // x[m] = sub-coefficient lane + 64 m of this half (u on wave 0, v on wave 1), |x| <= P/2
 #pragma unroll
-            for (int m = 0; m < R; m++) myx[lane + 64 * m] = x[m];
+            for (int m = 0; m < R; m++) lds_st(&myx[lane + 64 * m], x[m]);      // cross-wave payload: relaxed atomics, as in the FFT halves kernel
             halves_sync();
             uint32_t* poly = accbuf + comp * N + H * HN;
             // the branch on the (wave-uniform) half stays outside the point loop (inside it: one branch and one LDS wait per point)
             if (H) {
 #pragma unroll
-                for (int m = 0; m < R; m++) x[m] = ntt::normalize(ntt::modmul(x[m] - otx[lane + 64 * m], zc));     // zeta_1^-1 (u - v) = zeta_1 (v - u)
+                for (int m = 0; m < R; m++) x[m] = ntt::normalize(ntt::modmul(x[m] - lds_ld(&otx[lane + 64 * m]), zc));     // zeta_1^-1 (u - v) = zeta_1 (v - u)
             } else {
 #pragma unroll
-                for (int m = 0; m < R; m++) x[m] = ntt::normalize(x[m] + otx[lane + 64 * m]);
+                for (int m = 0; m < R; m++) x[m] = ntt::normalize(x[m] + lds_ld(&otx[lane + 64 * m]));
             }
 #pragma unroll
             for (int m = 0; m < R; m++) {

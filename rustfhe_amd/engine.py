@@ -4,6 +4,7 @@ Every compute method runs the HIP kernels of librtfhe_hip.so through the C ABI; 
 RtfheError with the library's message.  No CPU path exists in this package.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -26,11 +27,23 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
 
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def reference_twiddle_file(N):
+    """The shipped twiddle tables of the reference build the golden vectors were made with (rustfhe_amd/assets/), or None."""
+    path = os.path.join(ASSETS, "twiddles_N%d.bin" % N)
+    return path if os.path.exists(path) else None
+
+
 class Engine:
-    def __init__(self, params=None, device=0, devices=None):
+    def __init__(self, params=None, device=0, devices=None, reference_twiddles=True):
         """device: one GPU (rtfhe_ctx_create).  devices=[d0, d1, ...]: one context over several GPUs of the node
         (rtfhe_ctx_create_multi): keys are loaded once and replicated device-to-device, the host-buffer batch calls shard
-        contiguous gate ranges over them; *_dev and stage-level calls stay on devices[0]."""
+        contiguous gate ranges over them; *_dev and stage-level calls stay on devices[0].
+        reference_twiddles: the context builds its twiddle tables with this host's libm; when that libm disagrees with the shipped
+        tables of the reference build (a few entries may be an ulp apart between libms) the shipped tables are installed
+        instead (rtfhe_twiddles_load) and self.twiddle_entries_replaced says how many entries differed.  False: this host's libm as it is."""
         self.L = _ffi.load()
         self.p = params or Params()
         h = C.c_void_p()
@@ -44,6 +57,19 @@ class Engine:
             raise RtfheError(rc, (self.L.rtfhe_last_error(None) or b"").decode())
         self.h = h
         self.device = device
+        self.twiddle_entries_replaced = 0
+        path = reference_twiddle_file(self.p.N) if reference_twiddles else None
+        if path:
+            self.twiddle_entries_replaced = self.twiddles_load(path)
+
+    def twiddles_load(self, path):
+        """rtfhe_twiddles_load: installs the file's tables if they differ from the context's; returns the number of differing entries."""
+        n = C.c_int32(0)
+        self._ck(self.L.rtfhe_twiddles_load(self.h, os.fsencode(path), C.byref(n)))
+        return n.value
+
+    def twiddles_write(self, path):
+        self._ck(self.L.rtfhe_twiddles_write(self.h, os.fsencode(path)))
 
     def device_count(self):
         return self.L.rtfhe_ctx_device_count(self.h)
@@ -241,6 +267,66 @@ class Engine:
         res = np.empty(src.shape, np.uint32)
         self._ck(self.L.rtfhe_fft_u32_batch(self.h, _ptr(src), _ptr(res), src.shape[0]))
         return res
+
+
+class FftPlan:
+    """rtfhe_fft_plan: the reference's two transforms (and Spqlios_poly_mul) at any power of two 16 <= N <= 2048 on the GPU
+    (FFT_Processor_Spqlios(N), utils/src/spqlios/fft_processor_spqlios.cpp:7-14); numpy in / numpy out.  The gate path's N = 1024 /
+    2048 have their own, fast kernels behind Engine; this serves every other size the reference's FFT FFI accepts."""
+
+    def __init__(self, N, device=0):
+        self.L = _ffi.load()
+        self.N = int(N)
+        h = C.c_void_p()
+        rc = self.L.rtfhe_fft_plan_create(self.N, device, C.byref(h))
+        if rc != 0:
+            raise RtfheError(rc, (self.L.rtfhe_last_error(None) or b"").decode())
+        self.h = h
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RtfheError(rc, (self.L.rtfhe_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rtfhe_fft_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _run(self, fn, src, in_dtype, out_dtype, src2=None):
+        src = _np(src, in_dtype).reshape(-1, self.N)
+        res = np.empty(src.shape, out_dtype)
+        if src2 is None:
+            self._ck(fn(self.h, _ptr(src), _ptr(res), src.shape[0]))
+        else:
+            src2 = _np(src2, in_dtype).reshape(src.shape)
+            self._ck(fn(self.h, _ptr(src), _ptr(src2), _ptr(res), src.shape[0]))
+        return res
+
+    def ifft_i32(self, src):
+        return self._run(self.L.rtfhe_fft_plan_ifft_i32, src, np.int32, np.float64)
+
+    def ifft_f64(self, src):
+        return self._run(self.L.rtfhe_fft_plan_ifft_f64, src, np.float64, np.float64)
+
+    def fft_u32(self, src):
+        return self._run(self.L.rtfhe_fft_plan_fft_u32, src, np.float64, np.uint32)
+
+    def fft_f64(self, src):
+        return self._run(self.L.rtfhe_fft_plan_fft_f64, src, np.float64, np.float64)
+
+    def poly_mul(self, a, b):
+        return self._run(self.L.rtfhe_fft_plan_poly_mul, a, np.uint32, np.uint32, b)
+
+    def get_twiddles(self):
+        ifft, fft = np.empty(2 * self.N, np.float64), np.empty(2 * self.N, np.float64)
+        self._ck(self.L.rtfhe_fft_plan_get_twiddles(self.h, _ptr(ifft), _ptr(fft)))
+        return ifft, fft
+
+    def set_twiddles(self, ifft_table, fft_table):
+        a, b = _np(ifft_table, np.float64).reshape(2 * self.N), _np(fft_table, np.float64).reshape(2 * self.N)
+        self._ck(self.L.rtfhe_fft_plan_set_twiddles(self.h, _ptr(a), _ptr(b)))
 
 
 def pinned_empty(shape, dtype=np.uint32):

@@ -182,6 +182,9 @@ struct KeySwitchingKey {
         return TLWERep<M>::from_flat(flat.data() + (((size_t)i * TLWEHelper::IKS_L + l) * TLWEHelper::IKS_T + (t - 1)) * (M + 1));
     }
     const uint32_t* raw_ref() const { return flat.data(); }       // feeds rtfhe_load_ksk_ref
+    // Round 2's raw() returned the 3-entry layout of rtfhe_load_ksk; since round 3 the container is the reference's 4-entry one.  An out-of-tree
+    // caller that still writes rtfhe_load_ksk(ctx, ksk.raw()) must not compile into a mis-strided key: the name is kept, deleted.
+    const uint32_t* raw() const = delete;
 };
 
 }  // namespace hom_nand

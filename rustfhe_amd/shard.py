@@ -35,8 +35,9 @@ class ShardedGates:
             dist.broadcast(h, src=self._peer(self.root), group=self.group)
         return int(h[0].item()), bool(h[1].item())
 
-    def _scatter(self, fulls, parts):
-        """fulls: list of full [count, width] tensors on the root (None elsewhere).  Returns this rank's rows of each."""
+    def _post_scatter(self, fulls, parts):
+        """Root: posts the sends of every other rank's rows (views of the full tensors: nothing is staged) and returns (works, own rows)
+        WITHOUT waiting -- the root's own shard does not depend on them.  Other ranks: receive their rows and wait."""
         lo, hi = parts[self.rank]
         if self.rank == self.root:
             ops, mine = [], []
@@ -46,46 +47,45 @@ class ShardedGates:
                     if r != self.root and e > b:
                         ops.append(dist.P2POp(dist.isend, f[b:e], self._peer(r), self.group))
                 mine.append(f[lo:hi])
-        else:
-            mine = [torch.empty((hi - lo, self.width), dtype=torch.int32, device=self.device) for _ in fulls]
-            ops = [dist.P2POp(dist.irecv, m, self._peer(self.root), self.group) for m in mine] if hi > lo else []
+            return (dist.batch_isend_irecv(ops) if ops else []), mine
+        mine = [torch.empty((hi - lo, self.width), dtype=torch.int32, device=self.device) for _ in fulls]
+        ops = [dist.P2POp(dist.irecv, m, self._peer(self.root), self.group) for m in mine] if hi > lo else []
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return mine
+        return [], mine
 
-    def _gather(self, out, parts):
-        """out: this rank's [k, width] result.  Returns the full tensor on the root, None elsewhere."""
-        lo, hi = parts[self.rank]
-        if self.rank != self.root:
-            if hi > lo:
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, self._peer(self.root), self.group)]):
-                    w.wait()
-            return None
+    def _post_gather(self, parts):
+        """Root only: the full output tensor and the (un-waited) receives of every other rank's rows into views of it."""
         full = torch.empty((parts[-1][1], self.width), dtype=torch.int32, device=self.device)
-        full[lo:hi] = out
         ops = [dist.P2POp(dist.irecv, full[b:e], self._peer(r), self.group)
                for r, (b, e) in enumerate(parts) if r != self.root and e > b]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return full
+        return full, (dist.batch_isend_irecv(ops) if ops else [])
 
     def run(self, op, in0, in1, count, sync=None):
         """in0/in1: full [count, n+1] int32 tensors on the root (ignored elsewhere; in1 None for a unary gate).
         Returns the full output on the root, None on the other ranks.  With `sync` (a callable that drains this rank's
-        device queue) the scatter / compute / gather times of this call are left in self.last_timing (seconds)."""
+        device queue) the scatter / compute / gather times of this call are left in self.last_timing (seconds).
+
+        The root does not serialise scatter -> compute -> gather (round 4): it POSTS the sends, launches the bootstrap of its own shard
+        (asynchronous on its stream), posts the receives of the results and only then waits -- its own shard never waits for the other
+        ranks' rows to leave.  The receives are posted AFTER the root's own launch on purpose: RCCL's receive kernel spins on its CUs until
+        the peers' data arrives (a whole batch later), and the bootstrap kernel needs every CU of the chip to itself (one workgroup per CU,
+        all of its LDS and registers) -- posted first, the receive would hold CUs that the root's own workgroups then queue behind.
+        On the root "scatter_s" is therefore the time to post, and "gather_s" the wait that remains after its own compute."""
         import time
         count, has_in1 = self._header(count, in1 is not None)
         parts = partition(count, self.world)
         lo, hi = parts[self.rank]
+        root = self.rank == self.root
         t0 = time.perf_counter()
+        sends, recvs, full = [], [], None
         if self.world == 1:
             mine = [t.to(self.device) for t in ([in0] + ([in1] if has_in1 else []))]
         else:
-            fulls = ([in0] + ([in1] if has_in1 else [])) if self.rank == self.root else [None] * (2 if has_in1 else 1)
-            mine = self._scatter(fulls, parts)
-        if sync:
+            fulls = ([in0] + ([in1] if has_in1 else [])) if root else [None] * (2 if has_in1 else 1)
+            sends, mine = self._post_scatter(fulls, parts)
+        if sync and not root:
             sync()
         t1 = time.perf_counter()
         if hi > lo:
@@ -95,7 +95,18 @@ class ShardedGates:
         if sync:
             sync()
         t2 = time.perf_counter()
-        full = out if self.world == 1 else self._gather(out, parts)
+        if self.world == 1:
+            full = out
+        elif root:
+            full, recvs = self._post_gather(parts)
+            full[lo:hi] = out
+            for w in sends + recvs:
+                w.wait()
+        else:
+            if hi > lo:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, self._peer(self.root), self.group)]):
+                    w.wait()
+            full = None
         if sync:
             sync()
             self.last_timing = {"scatter_s": t1 - t0, "compute_s": t2 - t1, "gather_s": time.perf_counter() - t2}

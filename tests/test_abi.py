@@ -252,3 +252,30 @@ def test_wire_format_roundtrip_and_corruption(tmp_path):
         R.load_keys(path)
     with pytest.raises(R.RtfheError):
         R.load_tlwe(pub)
+
+
+def test_shipped_twiddle_tables_are_the_golden_reference_tables():
+    """rustfhe_amd/assets/twiddles_N*.bin (loaded through rtfhe_twiddles_load when a host's libm disagrees) hold exactly the tables
+    of the reference build the golden vectors were made with, in the table-file format of rtfhe_wire.cpp, checksum included; and the
+    oracle's own tables on THIS host agree with them (this image's libm is the reference build's)."""
+    import struct
+    import sys
+    import numpy as np
+    import rustfhe_amd as R
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    for N in (1024, 2048):
+        path = R.engine.reference_twiddle_file(N)
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"RTFHETW1" and struct.unpack("<ii", raw[8:16]) == (N, 0) and len(raw) == 16 + 4 * N * 8 + 8
+        h = 0xcbf29ce484222325
+        for x in raw[:-8]:
+            h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        assert struct.unpack("<Q", raw[-8:])[0] == h
+        g = np.load(os.path.join(ROOT, "tests", "golden", "fft_N%d.npz" % N))
+        assert raw[16:16 + 2 * N * 8] == g["ifft_table"].tobytes() and raw[16 + 2 * N * 8:-8] == g["fft_table"].tobytes()
+        a, b = orc.Plan(N).tables()
+        assert a.tobytes() == g["ifft_table"].tobytes() and b.tobytes() == g["fft_table"].tobytes()
+    L = R.load()
+    assert L.rtfhe_twiddles_load(None, b"/nonexistent", None) == R._ffi.ERR_INVALID
+    assert L.rtfhe_twiddles_write(None, b"/nonexistent") == R._ffi.ERR_INVALID

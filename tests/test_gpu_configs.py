@@ -468,3 +468,38 @@ def test_batches_on_two_streams_of_one_context_do_not_share_scratch(engine, keys
         engine.sync(s0.cuda_stream); engine.sync(s1.cuda_stream)
         assert np.array_equal(o0.cpu().numpy().view(np.uint32), ref0)
         assert np.array_equal(o1.cpu().numpy().view(np.uint32), ref1)
+
+
+def test_a_callers_own_stream_capture_survives_a_later_larger_batch_on_that_stream(engine, keys):
+    """A batch enqueued inside a CALLER'S stream capture must not bake the stream's split-path scratch pointer into the caller's graph
+    (round-3 advisor finding): a later, larger eager batch on that stream frees and reallocates the buffer, and a replay would then write
+    freed memory.  Inside a foreign capture the library therefore launches the fused kernel (one node, no scratch).  Capture a small batch,
+    grow the stream's scratch with a much larger eager batch, replay the graph twice: same words as the eager path."""
+    import torch
+    import rustfhe_amd as R
+    rng = np.random.default_rng(4242)
+    small, large = 300, 3000
+    bits = rng.integers(0, 2, (2, large))
+    c0 = torch.from_numpy(keys.encrypt_bits(bits[0]).view(np.int32)).cuda()
+    c1 = torch.from_numpy(keys.encrypt_bits(bits[1]).view(np.int32)).cuda()
+    ref = engine.gate_batch(R.NAND, c0[:small].cpu().numpy().view(np.uint32), c1[:small].cpu().numpy().view(np.uint32))
+    s = torch.cuda.Stream()
+    out_small, out_large = torch.zeros_like(c0[:small]), torch.empty_like(c0)
+    with torch.cuda.stream(s):
+        engine.gate_batch_dev(R.NAND, c0, c1, out_small, small, s.cuda_stream)         # the stream now owns a scratch buffer for >= 1024 gates
+        engine.sync(s.cuda_stream)
+        assert np.array_equal(out_small.cpu().numpy().view(np.uint32), ref)
+        out_small.zero_()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            engine.gate_batch_dev(R.NAND, c0, c1, out_small, small, s.cuda_stream)
+        launches_per_capture = 1                                                       # fused: one kernel node
+        engine.gate_batch_dev(R.NAND, c0, c1, out_large, large, s.cuda_stream)         # grows (frees + reallocates) the stream's scratch
+        engine.sync(s.cuda_stream)
+        for _ in range(2):
+            out_small.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(out_small.cpu().numpy().view(np.uint32), ref)
+    assert list(R.decrypt_bits(engine.p, keys.key0, out_large.cpu().numpy().view(np.uint32))) == list(1 - (bits[0] & bits[1]))
+    assert launches_per_capture == 1

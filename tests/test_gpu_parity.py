@@ -17,12 +17,60 @@ def test_native_library_is_loaded(engine):
 
 
 def test_twiddles_match_reference_tables(engine, orc, params):
+    """The tables this host's libm builds (reference_twiddles=False: no shipped table is consulted) are the reference build's, byte for
+    byte; so the session engine found nothing to replace when it checked the shipped tables."""
+    import rustfhe_amd as R
     g = golden("fft_N1024.npz")
-    a, b = engine.twiddles()
+    raw = R.Engine(engine.p, 0, reference_twiddles=False)
+    try:
+        a, b = raw.twiddles()
+    finally:
+        raw.close()
     assert a.tobytes() == g["ifft_table"].tobytes()
     assert b.tobytes() == g["fft_table"].tobytes()
     oa, ob = orc.Plan(params.N).tables()
     assert a.tobytes() == oa.tobytes() and b.tobytes() == ob.tobytes()
+    assert engine.twiddle_entries_replaced == 0
+    assert engine.twiddles()[0].tobytes() == a.tobytes()
+
+
+def test_a_host_libm_that_disagrees_is_overridden_by_the_shipped_reference_tables(keys, gold_gate, monkeypatch, tmp_path):
+    """the twiddle tables are libm outputs, two libms may differ by an ulp in a few entries, and one differing entry changes
+    torus words.  RTFHE_TEST_PERTURB_TWIDDLE moves ONE entry of the table the context builds by one ulp (a stand-in for such a host).
+    Left alone, that context no longer reproduces the reference build's tables (nor, in general, its spectra); the default engine notices the
+    disagreement with rustfhe_amd/assets/twiddles_N1024.bin, installs the shipped tables and reproduces the golden gates word for word."""
+    import rustfhe_amd as R
+    g = golden("fft_N1024.npz")
+    monkeypatch.setenv("RTFHE_TEST_PERTURB_TWIDDLE", "37")
+    p = R.Params()
+    raw = R.Engine(p, 0, reference_twiddles=False)
+    fixed = R.Engine(p, 0)
+    try:
+        ra, rb = raw.twiddles()
+        assert int((ra.view(np.uint64) != g["ifft_table"].view(np.uint64)).sum()) == 1 and rb.tobytes() == g["fft_table"].tobytes()
+        raw.load_bk_torus(keys.bk_t)
+        assert raw.export_bk_fft().tobytes() != keys.bk_f.tobytes()            # the perturbed entry reaches the key spectra
+        assert fixed.twiddle_entries_replaced == 1
+        fa, fb = fixed.twiddles()
+        assert fa.tobytes() == g["ifft_table"].tobytes() and fb.tobytes() == g["fft_table"].tobytes()
+        fixed.load_bk_torus(keys.bk_t)
+        fixed.load_ksk(keys.ksk)
+        assert fixed.export_bk_fft().tobytes() == keys.bk_f.tobytes()
+        ops, in0, in1 = gold_gate["ops"], gold_gate["in0"], gold_gate["in1"]
+        for k in range(len(ops)):
+            assert np.array_equal(fixed.gate_batch(int(ops[k]), in0[k:k + 1], in1[k:k + 1])[0], gold_gate["out"][k]), "gate %d" % k
+        # the file round trip: what the fixed context writes is the shipped file, and loading it into the raw context repairs that one too
+        path = str(tmp_path / "tw.bin")
+        fixed.twiddles_write(path)
+        assert open(path, "rb").read() == open(R.engine.reference_twiddle_file(1024), "rb").read()
+        assert raw.twiddles_load(path) == 1 and raw.twiddles_load(path) == 0
+        assert raw.export_bk_fft().tobytes() == keys.bk_f.tobytes()            # the torus-form key was re-transformed
+        with open(path, "r+b") as f:                                            # a corrupted file is refused
+            f.seek(100); f.write(b"\x01")
+        with pytest.raises(R.RtfheError):
+            raw.twiddles_load(path)
+    finally:
+        raw.close(); fixed.close()
 
 
 def test_forward_transform_golden_and_oracle(engine, orc, params):

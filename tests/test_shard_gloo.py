@@ -55,7 +55,8 @@ def _worker(rank, world, port, count, q, op_name="NAND"):
     if rank == 0:
         o = out.numpy().view(np.uint32)
         a0 = in0.numpy().view(np.uint32)
-        exp = np.stack([orc.gate(P, pl, op, K.bk_f, None, K.ksk, x, y) for x, y in zip(a0, a0 if unary else in1.numpy().view(np.uint32))])
+        exp = np.stack([orc.gate(P, pl, op, K.bk_f, None, K.ksk, x, y) for x, y in zip(a0, a0 if unary else in1.numpy().view(np.uint32))]) \
+            if count else np.empty((0, P.n + 1), np.uint32)
         want = {"NAND": 1 - (bits[0] & bits[1]), "NOT": 1 - bits[0], "COPY": bits[0]}[op_name]
         res = (bool(np.array_equal(o, exp)), K.decrypt_bits(o) == list(want), partition(count, world))
     else:
@@ -82,6 +83,28 @@ def test_scatter_bootstrap_gather_world2(count, op_name):
     same, dec_ok, parts = res
     assert same and dec_ok
     assert parts[0][0] == 0 and parts[-1][1] == count and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+@pytest.mark.parametrize("count", [7, 2, 0])
+def test_scatter_bootstrap_gather_world3_ragged_and_empty_ranks(count):
+    """World size 3: 7 gates = 2 + 2 + 3 (ragged); 2 gates = 0 + 1 + 1 -- the ROOT itself gets no gate and still scatters and gathers;
+    0 gates: nobody computes, everybody returns.  The root posts its sends and receives before it computes (shard.py: run)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, count, q, "NAND")) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    same, dec_ok, parts = res
+    assert same and dec_ok
+    sizes = [e - b for b, e in parts]
+    assert sum(sizes) == count and max(sizes) - min(sizes) <= 1
+    if count == 2:
+        assert sizes == [0, 1, 1]
 
 
 def test_partition_properties():
