@@ -169,7 +169,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #define HALVES_SYNC() pair_sync(my_flag, partner_flag, ++sync_k)
 #endif
 #define HALVES_ARRIVE() pair_arrive(my_flag, ++sync_k)
+#ifdef HALVES_OPAQUE_WAIT      // A/B: the spin loop inside one inline-assembly statement (no loop header in the compiler's control-flow graph)
+#define HALVES_WAIT() pair_wait_opaque(partner_flag, sync_k)
+#else
 #define HALVES_WAIT() pair_wait(partner_flag, sync_k)
+#endif
 #ifdef HALVES_ABL_NOSYNC       // timing ablation only (racy, wrong results)
 #undef HALVES_SYNC
 #define HALVES_SYNC() wave_lds_sync()
@@ -337,6 +341,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 for (int m = 0; m < R; m++) { lds_st(&wb[ln + 64 * m], xr[m]); lds_st(&wb[G::XSLOTS + ln + 64 * m], xi[m]); }
                 HALVES_ARRIVE();
                 if (HALVES_EARLY_ROW && jj + 1 < L) own_row2(jj + 1);
+#ifdef HALVES_EARLY_PASS1     // A/B: the last row's wait has no own products left to cover it: pass 1 of the sub-transforms of rows 0, 1 goes there
+                if (jj == L - 1) {
+                    Tw<R - 1> w1e;
+                    w1e.load(tw_sub + G::TW_P1 + ln, 64);
+#pragma unroll
+                    for (int j2 = 0; j2 < L - 1; j2++) P12<R, G::LR - 1>::fwd(yr[j2], yi[j2], w1e.w);
+                }
+#endif
                 HALVES_WAIT();
                 if (H == 0) {                           // mine = x0, partner's = x1
 #pragma unroll
@@ -438,7 +450,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             HV_STAMP(1);
             prio_point(1);
             // the 512-point sub-transforms of the three rows side by side
+#ifdef HALVES_EARLY_PASS1
+            if constexpr (SPLIT1 && PINGPONG) fft_forward_multi_a<10, L, false, NoHook, false, L - 1>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
+            else fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
+#else
             fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
+#endif
             prio_point(2);
 #ifndef HALVES_FETCH_LATE
             fetch(bA, i, h * 2 * L);                    // (row 0, comp 0) of this polynomial: in flight under the last pass

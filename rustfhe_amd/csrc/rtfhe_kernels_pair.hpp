@@ -92,6 +92,23 @@ __device__ __forceinline__ void pair_wait(unsigned partner_flag_addr, unsigned k
     } while ((int)(v - k) < 0);
 }
 
+// pair_wait as ONE opaque statement: the spin loop lives inside the inline assembly, so the compiler sees straight-line code (a wait in the
+// middle of a multiply-accumulate slot, with 200 registers live across it, otherwise becomes a loop header and the allocator spilled 88 of them)
+__device__ __forceinline__ void pair_wait_opaque(unsigned partner_flag_addr, unsigned k) {
+    unsigned v, t;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %1, %0\n\t"
+        "s_sub_i32 %1, %1, %3\n\t"
+        "s_cmp_lt_i32 %1, 0\n\t"
+        "s_cbranch_scc1 1b"
+        : "=&v"(v), "=&s"(t)
+        : "v"(partner_flag_addr), "s"(k)
+        : "memory", "scc");
+}
+
 template <int R>
 __device__ __forceinline__ void mac_row_first(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
 #pragma unroll
@@ -373,7 +390,19 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
         prio_point(6);
         PAIR_STAMP(4);
+#ifdef PAIR_EARLY_Q
+        // Split-phase hand-off 1 (round 4).  What each side needs at this point differs: side 1 needs hand0 (side 0's slot P) BEFORE its slot Q;
+        // side 0 needs nothing for its slot-Q arithmetic (its own rows, its own key rows) -- only the buffer its result goes to (hand1 = side
+        // 1's exchange buffers) must be idle, i.e. side 1 must have finished its transforms, BEFORE the put.  Both arrive here; side 1 waits
+        // here, side 0 waits in front of its put.  The stamps of round 3 had side 0 parked 2.5-2.8 k cycles per step at the barrier that stood
+        // here while side 1 (the lower-priority wave during the transforms) ran alone.
+        // (the same code on both sides -- a wait behind a branch on the side made the allocator spill 91 registers: the side that need not wait
+        // polls its OWN counter, which it has just advanced)
+        pair_arrive(my_flag, 2u * (unsigned)i + 1u);
+        pair_wait_opaque(side ? partner_flag : my_flag, 2u * (unsigned)i + 1u);
+#else
         if constexpr (FLAG_A) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u); else lds_barrier();
+#endif
         prio_point(7);
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
@@ -384,10 +413,18 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         mac_row<R>(sre, sim, bA, xr[0], xi[0]); fetch(bA, i, side ? 2 : 5);
         mac_row<R>(sre, sim, bB, xr[1], xi[1]); fetch(bB, side ? i : nxt, side ? 3 : 0);
         mac_row<R>(sre, sim, bA, xr[2], xi[2]); fetch(bA, side ? i : nxt, side ? 4 : 1);
+#ifdef PAIR_EARLY_Q
+        pair_wait_opaque(side ? my_flag : partner_flag, 2u * (unsigned)i + 1u);     // side 0: hand1 is side 1's exchange buffer pair, idle once side 1 has arrived
+#endif
         put(side ? hand0 : hand1);
         prio_point(8);
         PAIR_STAMP(6);
+#ifdef PAIR_EARLY_Q
+        pair_arrive(my_flag, 2u * (unsigned)i + 2u);
+        pair_wait_opaque(partner_flag, 2u * (unsigned)i + 2u);
+#else
         if constexpr (FLAG_B) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();
+#endif
         prio_point(9);
         PAIR_STAMP(7);
         // slot R (side 1): component 1 over rows 3..5 on top of side 0's partial sum; side 0 picks up the finished s0

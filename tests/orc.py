@@ -418,6 +418,8 @@ def host_topology():
             break
         except (OSError, ValueError, IndexError, ZeroDivisionError):
             continue
+    if os.environ.get("RTFHE_TEST_CPU_QUOTA"):          # tests: pretend the cgroup grants this many cores
+        quota = float(os.environ["RTFHE_TEST_CPU_QUOTA"])
     first_of_core = {}
     for cpu in threads:
         first_of_core.setdefault(core_of.get(cpu, ("0", str(cpu))), cpu)

@@ -208,6 +208,23 @@ def test_cpu_baseline_child_measures_tiled_batches_on_pinned_threads(baseline_in
     assert not os.path.exists(child.dir)                        # the scratch directory is gone
 
 
+def test_cpu_baseline_child_respects_a_cgroup_cpu_quota(baseline_inputs, monkeypatch):
+    """The GPU boxes of this pool show 256 hardware threads and grant 16 cores of CPU time (cpu.max): the run of record then uses
+    ceil(quota) pinned threads, and its efficiency is measured against the cores it was entitled to."""
+    import bench
+    np, P, bk, ksk, in0, in1, exp = baseline_inputs
+    if len(os.sched_getaffinity(0)) < 4:
+        pytest.skip("needs >= 4 CPUs")
+    monkeypatch.setenv("RTFHE_BENCH_CPU_TARGET_S", "0.2")
+    monkeypatch.setenv("RTFHE_TEST_CPU_QUOTA", "2")
+    res = bench.CpuBaselineChild(np, P, bk, ksk, in0, in1, 3).collect(exp, timeout=600)
+    assert "error" not in res, res
+    leg = res.get("port", res)
+    assert [r["threads"] for r in leg["runs"]] == ["cgroup_cpu_quota_cores_one_thread_each", "one_thread_per_physical_core"]
+    assert leg["runs"][0]["threads_used"] == 2 and leg["runs"][0]["cores_entitled"] == 2 and leg["runs"][1]["cores_entitled"] == 2
+    assert res["host"]["cgroup_cpu_quota_cores"] == 2.0 and res["matches_gpu_bit_exact"] is True
+
+
 def test_cpu_baseline_child_abort_is_an_error_entry_not_a_lost_line(baseline_inputs, monkeypatch):
     import bench
     np, P, bk, ksk, in0, in1, exp = baseline_inputs
