@@ -20,6 +20,7 @@
 #include "rtfhe_kernels_wg.hpp"
 #include "rtfhe_kernels_pair.hpp"
 #include "rtfhe_kernels_halves.hpp"
+#include "rtfhe_kernels_eo.hpp"
 #include "rtfhe_kernels_ntt.hpp"
 #include "rtfhe_kernels_ntt_halves.hpp"
 #include "rtfhe_kernels_anyn.hpp"
@@ -159,6 +160,47 @@ struct HostTw {
         return t;
     }
 
+    // table of k_bootstrap_eo (N = 2048; layout: EoTw): wave H owns the points i = 2 j + H and runs nine of the ten stages on the 512-point
+    // sub-sequence j; the twiddle of pair (i, i + halfnn) is entry i mod halfnn = 2 (j mod halfnn / 2) + H of the reference's stage table
+    std::vector<cplx> eo_table() const {
+        typedef Geo<10> G;
+        std::vector<cplx> t(EoTw::TOTAL, make_double2(0.0, 0.0));
+        const double fold = 2.0 / (double)N;      // the inverse's input scaling (fft_processor_spqlios.cpp:158), exact, folded into the untwist
+        for (int H = 0; H < 2; H++) {
+            for (int m = 0; m < 8; m++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = 2 * (lane + 64 * m) + H;
+                    t[EoTw::TWIST + (H * 8 + m) * 64 + lane] = make_double2(twist_c[i], twist_s[i]);
+                    t[EoTw::IUNTW + (H * 8 + m) * 64 + lane] = make_double2(untw_c[i] * fold, untw_s[i] * fold);
+                }
+            for (int mb = G::LR - 1; mb >= 0; mb--) {
+                const int h = 1 << mb;
+                for (int q = 0; q < h; q++) {
+                    const int e = G::R - 2 * h + q;
+                    for (int lane = 0; lane < 64; lane++) {           // pass 1: j-halfnn 64 h = i-halfnn 128 h
+                        const int k = 2 * (lane + 64 * q) + H;
+                        t[EoTw::P1 + (H * 7 + e) * 64 + lane] = make_double2(fwd_c[fwd_off(128 * h) + k], fwd_s[fwd_off(128 * h) + k]);
+                        t[EoTw::IP1 + (H * 7 + e) * 64 + lane] = make_double2(inv_c[inv_off(128 * h) + k], inv_s[inv_off(128 * h) + k]);
+                    }
+                    for (int r = 0; r < G::NLOW; r++) {               // pass 2: j-halfnn 8 h = i-halfnn 16 h
+                        const int k = 2 * ((q << G::LOW) | r) + H;
+                        t[EoTw::P2 + (H * 7 + e) * G::NLOW + r] = make_double2(fwd_c[fwd_off(16 * h) + k], fwd_s[fwd_off(16 * h) + k]);
+                        t[EoTw::IP2 + (H * 7 + e) * G::NLOW + r] = make_double2(inv_c[inv_off(16 * h) + k], inv_s[inv_off(16 * h) + k]);
+                    }
+                }
+            }
+            for (int q = 0; q < 4; q++) {                             // pass 3: i-halfnn 8 (entries 0..3) and 4 (entries 4..5)
+                t[EoTw::P3 + H * 8 + q] = make_double2(fwd_c[fwd_off(8) + 2 * q + H], fwd_s[fwd_off(8) + 2 * q + H]);
+                t[EoTw::IP3 + H * 8 + q] = make_double2(inv_c[inv_off(8) + 2 * q + H], inv_s[inv_off(8) + 2 * q + H]);
+            }
+            for (int q = 0; q < 2; q++) {
+                t[EoTw::P3 + H * 8 + 4 + q] = make_double2(fwd_c[fwd_off(4) + 2 * q + H], fwd_s[fwd_off(4) + 2 * q + H]);
+                t[EoTw::IP3 + H * 8 + 4 + q] = make_double2(inv_c[inv_off(4) + 2 * q + H], inv_s[inv_off(4) + 2 * q + H]);
+            }
+        }
+        return t;
+    }
+
     // device table: per direction [twist R*64][pass1 (R-1)*64][pass2 (R-1)*NLOW][pass3 NLOW-4]
     template <int LOGN>
     std::vector<cplx> device_table() const {
@@ -217,6 +259,10 @@ struct rtfhe_ctx {
     cplx* d_bk = nullptr;
     cplx* d_htw = nullptr;            // N = 2048: tables of k_bootstrap_halves
     cplx* d_hbk = nullptr;            // N = 2048: key spectra in the halves layout
+    cplx* d_etw = nullptr;            // N = 2048: tables of k_bootstrap_eo
+    cplx* d_ebk = nullptr;            // N = 2048: key spectra in the even / odd layout
+    int n2048_kernel = -1;            // -1 = by launch shape (below), 0 = parity split (k_bootstrap_eo), 1 = top-bit split (k_bootstrap_halves);
+                                      // RTFHE_N2048_KERNEL=eo|halves
     int backend = RTFHE_BACKEND_FFT64_MIRROR;
     uint32_t* d_bk_torus = nullptr;   // kept when the key came in torus form: source for the NTT-domain key
     double* d_ntt_bk = nullptr;
@@ -446,6 +492,27 @@ int launch_bootstrap_halves11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) 
     return 0;
 }
 
+// N = 2048: two waves per transform, split by the parity of the point index (rtfhe_kernels_eo.hpp)
+template <int GATES>
+int launch_bootstrap_eo11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_eo<3, 6, 8, 2, KSQ, GATES>;
+    const size_t lds = EoLds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    EoArgs a{b, ctx->d_etw, ctx->d_ebk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(128 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+template <int GATES>
+int launch_bootstrap_n2048_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    // Measured (profiles/r04/n2048_parity_split_ab.log, same process, identical outputs): where a workgroup holds 1-2 gates (a SIMD then hosts one
+    // wave, or two of one gate with the other SIMDs free) the parity split is 4-5 % faster -- its trades are covered by arithmetic; with 3-4 gates
+    // per workgroup (every SIMD two waves deep, the LDS half full of exchange traffic) the top-bit split is 1-2 % faster.
+    const bool eo = ctx->n2048_kernel < 0 ? GATES <= 2 : ctx->n2048_kernel == 0;
+    return eo ? launch_bootstrap_eo11_g<GATES>(ctx, b, s) : launch_bootstrap_halves11_g<GATES>(ctx, b, s);
+}
+
 // words per gate of the output buffer, by mode (MODE_EXTRACT: the final TLWE rows; the lvl1 samples go to `ext`)
 size_t mode_out_words(const BootstrapArgs& a, int N) {
     return a.mode == MODE_BLIND_ROTATE ? (size_t)2 * N : (size_t)a.n + 1;
@@ -502,13 +569,13 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
         if (full)
-            if (int rc = launch_bootstrap_halves11_g<4>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
+            if (int rc = launch_bootstrap_n2048_g<4>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
         if (!rem) return 0;
         const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
-        if (rem <= cus) return launch_bootstrap_halves11_g<1>(ctx, tail, s);
-        if (rem <= 2 * cus) return launch_bootstrap_halves11_g<2>(ctx, tail, s);
-        if (rem <= 3 * cus) return launch_bootstrap_halves11_g<3>(ctx, tail, s);
-        return launch_bootstrap_halves11_g<4>(ctx, tail, s);
+        if (rem <= cus) return launch_bootstrap_n2048_g<1>(ctx, tail, s);
+        if (rem <= 2 * cus) return launch_bootstrap_n2048_g<2>(ctx, tail, s);
+        if (rem <= 3 * cus) return launch_bootstrap_n2048_g<3>(ctx, tail, s);
+        return launch_bootstrap_n2048_g<4>(ctx, tail, s);
     }
 }
 
@@ -793,12 +860,15 @@ int launch_permute_t(rtfhe_ctx* ctx, const double* src, double* dst, size_t coun
 // builders produce holds.  A table imported through rtfhe_set_twiddles is checked here and refused otherwise.
 bool unit_twiddles_ok(const HostTw& tw) {
     auto is_zero = [](double v) { return v == 0.0; };
-    return tw.fwd_c[tw.fwd_off(4)] == 1.0 && is_zero(tw.fwd_s[tw.fwd_off(4)]) && tw.inv_c[tw.inv_off(4)] == 1.0 && is_zero(tw.inv_s[tw.inv_off(4)]);
+    // (k_bootstrap_eo, N = 2048, also skips the first butterfly of the halfnn = 8 stage of the even-point sub-network)
+    for (int h : {4, 8})
+        if (!(tw.fwd_c[tw.fwd_off(h)] == 1.0 && is_zero(tw.fwd_s[tw.fwd_off(h)]) && tw.inv_c[tw.inv_off(h)] == 1.0 && is_zero(tw.inv_s[tw.inv_off(h)]))) return false;
+    return true;
 }
 
 int upload_twiddles(rtfhe_ctx* ctx) {
     if (BOOT_TRIV && !unit_twiddles_ok(ctx->tw))
-        return fail(ctx, RTFHE_ERR_INVALID, "twiddle table: the first entry of the halfnn = 4 stage must be exactly (1, 0) in both directions "
+        return fail(ctx, RTFHE_ERR_INVALID, "twiddle table: the first entry of the halfnn = 4 and 8 stages must be exactly (1, 0) in both directions "
                                             "(cos 0, sin 0: true of every table the reference builds)");
     std::vector<cplx> t = ctx->logn == 10 ? ctx->tw.device_table<10>() : ctx->tw.device_table<11>();
     if (!ctx->d_tw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tw, t.size() * sizeof(cplx)));
@@ -807,6 +877,9 @@ int upload_twiddles(rtfhe_ctx* ctx) {
         std::vector<cplx> h = ctx->tw.halves_table();
         if (!ctx->d_htw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_htw, h.size() * sizeof(cplx)));
         HIPCHECK(ctx, hipMemcpy(ctx->d_htw, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice));
+        std::vector<cplx> e = ctx->tw.eo_table();
+        if (!ctx->d_etw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_etw, e.size() * sizeof(cplx)));
+        HIPCHECK(ctx, hipMemcpy(ctx->d_etw, e.data(), e.size() * sizeof(cplx), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -818,6 +891,9 @@ int build_halves_bk(rtfhe_ctx* ctx) {
     const size_t polys = bk_word_count(ctx->p) / ctx->p.N;
     if (!ctx->d_hbk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_hbk, bk_cplx_count(ctx->p) * sizeof(cplx)));
     hipLaunchKernelGGL(k_bk_to_halves, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, ctx->d_hbk, polys, 1.0);
+    HIPCHECK(ctx, hipGetLastError());
+    if (!ctx->d_ebk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_ebk, bk_cplx_count(ctx->p) * sizeof(cplx)));
+    hipLaunchKernelGGL(k_bk_to_eo, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, ctx->d_ebk, polys);
     HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -875,6 +951,10 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 3>, HalvesLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 2>, HalvesLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_halves<3, 6, 8, 2, KSQ, 1>, HalvesLds::bytes(1, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 4>, EoLds::bytes(4, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 3>, EoLds::bytes(3, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 2>, EoLds::bytes(2, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 1>, EoLds::bytes(1, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_halves<3, 6, 8, 2, KSQ, 4>, NttHalvesLds::bytes(4, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_halves<3, 6, 8, 2, KSQ, 3>, NttHalvesLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_halves<3, 6, 8, 2, KSQ, 2>, NttHalvesLds::bytes(2, npad))) return rc;
@@ -1021,6 +1101,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
         if (const char* e = std::getenv("RTFHE_WG_MAX_GATES")) ctx->wg_max = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_STAGING")) ctx->stage_pinned = std::atoi(e) != 0;
         if (const char* e = std::getenv("RTFHE_KS_MM_MIN")) ctx->ks_mm_min = std::atoi(e);
+        if (const char* e = std::getenv("RTFHE_N2048_KERNEL")) ctx->n2048_kernel = std::string(e) == "halves" ? 1 : std::string(e) == "eo" ? 0 : -1;
     }
     if (!rc) rc = prime_kernel_attributes(ctx);
     if (!rc) rc = upload_twiddles(ctx);
@@ -1107,6 +1188,8 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_bk) (void)hipFree(ctx->d_bk);
     if (ctx->d_htw) (void)hipFree(ctx->d_htw);
     if (ctx->d_hbk) (void)hipFree(ctx->d_hbk);
+    if (ctx->d_etw) (void)hipFree(ctx->d_etw);
+    if (ctx->d_ebk) (void)hipFree(ctx->d_ebk);
     if (ctx->d_bk_torus) (void)hipFree(ctx->d_bk_torus);
     if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
     if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);

@@ -1,0 +1,415 @@
+// rtfhe_kernels_eo.hpp -- N = 2048, two waves per transform, split by the PARITY of the point index (round 4).
+//
+// k_bootstrap_halves splits a 1024-point transform by its top index bit: the reference's first forward stage (halfnn = 512) then crosses the two
+// waves, and it is a TWIDDLED stage -- half B carries its 6 extra FP64 instructions per point, both halves stop three times per polynomial to
+// trade twisted inputs row by row with nothing to do meanwhile, and the same again at the end of the inverse (profiles/r03/n2048_phase_stamps.log:
+// the trade phases take 12 k of a 58.5 k-cycle step for ~1,000 of its 8,160 FP64 instructions, half B idles a quarter of the step).
+//
+// Here wave H owns the points of parity H: i = 2 j + H, j in [0, 512).  Every radix-2 stage of the reference network pairs i with i + halfnn
+// (forward, decimation in frequency, spqlios-fft-impl.cpp:526-572; inverse, decimation in time, :315-363), and for halfnn >= 2 both have the same
+// parity: NINE of the ten stages stay inside a wave -- twist, halfnn = 512 ... 4 (eight twiddled stages), and this parity's half of the size-4 stage
+// (:575-603 / :289-310) -- as a 512-point network in j of exactly the shape the N = 1024 kernels run (8 points per lane, three in-register passes of
+// three stages, two wave-private exchanges), with the twiddle of pair (i, i + halfnn) = entry (i mod halfnn) = 2 (j mod halfnn/2) + H of the
+// reference's stage table.  Only the size-2 stage (halfnn = 1: x0 + x1, x0 + (-x1), no twiddle, :606-634 / :248-269) crosses the waves: it is the LAST
+// stage of the forward transform and the FIRST of the inverse.  Consequences:
+//   * both waves execute the same instruction stream (wave 1's only differences: table pointers, and "partner + (-mine)" where wave 0 has
+//     "mine + partner") -- the work is balanced by construction, no priority schedule has anything to even out;
+//   * the forward trade comes after a row's pass 3: the NEXT row's pass 3 (and, for the last row, the first multiply-accumulates) run between
+//     a row's arrival flag and the wait for the partner's -- no wave ever sits at a synchronisation with nothing to issue;
+//   * gather, decomposition and twist are wave-private: no first-stage trade at all.
+// Each wave owns the spectrum points of its parity for the multiply-accumulate over all six rows and both components: the fold order
+// (trgsw.rs:290-299) holds trivially, no partial sums travel.  Buffer ownership ping-pongs as in k_bootstrap_halves (round 4): one arrival / wait per
+// trade, 3 per polynomial + 1 per inverse = 8 per step.  Same arithmetic DAG as the reference, every product and sum rounded on its own
+// (-ffp-contract=off): bit-identical to k_bootstrap_halves and k_bootstrap<11> (tests/test_gpu_configs.py::test_config5_*).
+// LDS: the per-parity stage tables of passes 1-3 (16 KiB forward, 2 KiB inverse); twist / untwist / inverse pass-1 tables in global memory.
+#pragma once
+
+#include <type_traits>
+
+#include "rtfhe_kernels_halves.hpp"
+
+#ifndef EO_PRIO_B
+#define EO_PRIO_B 0
+#endif
+
+namespace rtfhe {
+
+// twiddle table of the even / odd kernel, cplx units, everything [parity 0 | parity 1]
+struct EoTw {
+    static constexpr int TWIST = 0;                   // [2][8][64]  point i = 2 (lane + 64 m) + H                                   (global memory)
+    static constexpr int P1 = TWIST + 2 * 8 * 64;     // [2][7][64]  pass 1: j-halfnn 256, 128, 64, entry layout of Geo<10>::TW_P1      (LDS from here ...
+    static constexpr int P2 = P1 + 2 * 7 * 64;        // [2][7][8]   pass 2: j-halfnn 32, 16, 8
+    static constexpr int P3 = P2 + 2 * 7 * 8;         // [2][8]      pass 3: j-halfnn 4 (4 entries), 2 (2 entries), 2 pad
+    static constexpr int IP2 = P3 + 2 * 8;            // [2][7][8]   inverse pass 2
+    static constexpr int IP3 = IP2 + 2 * 7 * 8;       // [2][8]      inverse pass 3                                                    ... to here)
+    static constexpr int IP1 = IP3 + 2 * 8;           // [2][7][64]  inverse pass 1                                                    (global memory)
+    static constexpr int IUNTW = IP1 + 2 * 7 * 64;    // [2][8][64]  untwist, times 2/N                                               (global memory)
+    static constexpr int TOTAL = IUNTW + 2 * 8 * 64;
+    static constexpr int LDS_CPLX = IP1 - P1;
+};
+
+struct EoLds {
+    typedef Geo<10> G;
+    static constexpr size_t TW = (size_t)EoTw::LDS_CPLX * sizeof(cplx);
+    static constexpr size_t XB = HalvesLds::XB;
+    static constexpr size_t FLAGS = 16;
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + HalvesLds::abar_bytes(npad) + 2 * XB + FLAGS; }
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
+};
+
+struct EoArgs {
+    BootstrapArgs b;       // b.tw / b.bk unused
+    const cplx* etw;       // [EoTw::TOTAL]
+    const cplx* ebk;       // [n][2l rows][2 comp][2 parity][8][64]
+};
+
+// key spectra: device layout of k_bootstrap<11> ([n][row][comp][16][64]: lane v, register m <-> point (v << 4) | m) -> even / odd layout
+// (lane v, register m of parity H <-> point 2 (8 v + m) + H = (v << 4) | (2 m + H))
+__global__ __launch_bounds__(256) void k_bk_to_eo(const cplx* __restrict__ src, cplx* __restrict__ dst, size_t polys) {
+    const size_t total = polys * 1024;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = idx >> 10;
+        const int k = (int)(idx & 1023);                 // destination: (H, m, lane)
+        const int H = k >> 9, m = (k >> 6) & 7, lane = k & 63;
+        dst[idx] = src[g * 1024 + (size_t)(2 * m + H) * 64 + lane];
+    }
+}
+
+// pass 3 of a parity's sub-network, forward: i-halfnn 8 and 4 (twiddled, wave-uniform entries w[0..3] / w[4..5]), then this parity's half of the
+// size-4 stage (spqlios-fft-impl.cpp:581-602): even points x0, x2 -> x0 + x2, x0 + (-x2); odd points x1, x3 -> x1 + x3, i (x1 - x3) = ((-j1) + j3, r1 + (-r3))
+template <int R, bool ODD>
+__device__ __forceinline__ void eo_fwd_pass3(double (&re)[R], double (&im)[R], const cplx* w) {
+    fwd_stage_tw<R, 2, BOOT_TRIV && !ODD>(re, im, w);          // entry 0 of parity 0 is the reference's (1, 0): see fwd_stage_tw
+    fwd_stage_tw<R, 1, BOOT_TRIV && !ODD>(re, im, w + 4);
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double ra = re[m], rb = re[m + 1], ja = im[m], jb = im[m + 1];
+        if (!ODD) { re[m] = ra + rb; re[m + 1] = ra + (-rb); im[m] = ja + jb; im[m + 1] = ja + (-jb); }
+        else      { re[m] = ra + rb; re[m + 1] = (-ja) + jb; im[m] = ja + jb; im[m + 1] = ra + (-rb); }
+    }
+}
+// ... inverse: this parity's half of the size-4 stage (:289-310): even x0, x2 -> x0 + x2, x0 + (-x2); odd x1, x3 -> x1 - i x3 = (r1 + j3, j1 + (-r3)),
+// x1 + i x3 = (r1 + (-j3), j1 + r3); then i-halfnn 4 and 8
+template <int R, bool ODD>
+__device__ __forceinline__ void eo_inv_pass3(double (&re)[R], double (&im)[R], const cplx* w) {
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+        const double ra = re[m], rb = re[m + 1], ja = im[m], jb = im[m + 1];
+        if (!ODD) { re[m] = ra + rb; re[m + 1] = ra + (-rb); im[m] = ja + jb; im[m + 1] = ja + (-jb); }
+        else      { re[m] = ra + jb; re[m + 1] = ra + (-jb); im[m] = ja + (-rb); im[m + 1] = ja + rb; }
+    }
+    inv_stage_tw<R, 1, false, BOOT_TRIV && !ODD>(re, im, w + 4);
+    inv_stage_tw<R, 2, false, BOOT_TRIV && !ODD>(re, im, w);
+}
+
+template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
+__global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea) {
+    constexpr int LOGN = 11, N = 2048, P = 1024, R = 8, NT = 128 * GATES;
+    typedef Geo<10> G;   // geometry of a parity's 512-point sub-network
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    static_assert(L == 3, "three digit rows of a polynomial are transformed side by side");
+    const BootstrapArgs& a = ea.b;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave % GATES;          // the two parities of a gate share a SIMD (waves w, w + GATES)
+    const int H = wave / GATES;
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    for (int idx = tid; idx < EoTw::LDS_CPLX; idx += NT) tw[idx] = ea.etw[EoTw::P1 + idx];
+    // this parity's tables, addressed with Geo<10>'s per-direction offsets where a device function expects them
+    const cplx* tw_fwd12 = tw + (size_t)H * 7 * 64 - G::TW_P1;                                   // + G::TW_P1 -> P1[H]; P2 is not contiguous with it here:
+    const cplx* tw_p2 = tw + (EoTw::P2 - EoTw::P1) + (size_t)H * 7 * 8;
+    const cplx* tw_p3 = tw + (EoTw::P3 - EoTw::P1) + (size_t)H * 8;
+    const cplx* twi_p2 = tw + (EoTw::IP2 - EoTw::P1) + (size_t)H * 7 * 8;
+    const cplx* twi_p3 = tw + (EoTw::IP3 - EoTw::P1) + (size_t)H * 8;
+    const cplx* gtwist0 = ea.etw + EoTw::TWIST + (size_t)H * 8 * 64;     // global memory
+    const cplx* guntw0 = ea.etw + EoTw::IUNTW + (size_t)H * 8 * 64;
+    const cplx* gip10 = ea.etw + EoTw::IP1 + (size_t)H * 7 * 64;
+
+    const int g_raw = blockIdx.x * GATES + slot;
+    const int g = g_raw < a.count ? g_raw : a.count - 1;
+    const GateIo io = gate_io(a, g);
+    const bool live = g_raw < a.count && io.ok;
+
+    unsigned char* gbase = smem + EoLds::TW + (size_t)slot * EoLds::gate_bytes(a.npad);
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
+    uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
+    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + HalvesLds::abar_bytes(a.npad));
+    double* xb1 = xb0 + 2 * G::XSLOTS;
+    double* wbuf = H ? xb1 : xb0;     // the buffer pair this wave owns (writes next); ownership swaps after every trade
+    double* rbuf = H ? xb0 : xb1;     // the partner's (read after its arrival)
+    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + EoLds::gate_bytes(a.npad) - EoLds::FLAGS);
+    if (lane0 == 0) flags[H] = 0u;
+    const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + H);
+    const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - H));
+    unsigned sync_k = 0;
+#define EO_ARRIVE() pair_arrive(my_flag, ++sync_k)
+#define EO_WAIT() pair_wait_opaque(partner_flag, sync_k)
+
+    const int n = a.n;
+    {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
+        constexpr int SH = 32 - LOGN - 1;
+        for (int i = lane0 + 64 * H; i <= n; i += 128) {
+            const uint32_t t = gate_linear(io.op, io.p0[i], io.p1[i], i == n);
+            abar[i] = (uint16_t)((i == n) ? (t >> SH) : ((t + (1u << (SH - 1))) >> SH));
+        }
+    }
+    __syncthreads();
+    {   // acc = X^{-bbar} * testvec (tfhe.rs:85, 98-106); each wave initialises half of the words
+        const int bbar = (int)abar[n];
+        for (int c = lane0 + 64 * H; c < 2 * N; c += 128) {
+            const int e = (c + bbar) & (2 * N - 1);
+            accbuf[c] = c < N ? ((e >> LOGN) ? 0xE0000000u : 0x20000000u) : 0u;
+        }
+    }
+    __syncthreads();
+
+    // key rows in consumption order rc = 0..11 = (row rc / 2, component rc & 1) of this parity: the order of the layout.  Two buffers.
+    const size_t trgsw_cplx = (size_t)2 * L * 2 * 2 * R * 64;
+    cplx bA[R], bB[R];
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(ea.ebk), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane0 * 16;
+    auto fetch = [&](cplx (&dst)[R], int step, int rc) {
+        const size_t row = (size_t)step * trgsw_cplx + (size_t)rc * 2 * R * 64 + (size_t)H * R * 64;
+        const int s_lo = __builtin_amdgcn_readfirstlane((int)(row * sizeof(cplx)));
+        const int s_hi = s_lo + (R / 2) * 64 * (int)sizeof(cplx);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_lo, 0);
+            dst[m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+        }
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_hi, 0);
+            dst[R / 2 + m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (H) __builtin_amdgcn_s_setprio(EO_PRIO_B);
+#ifdef RTFHE_WG_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define EO_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[k] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EO_STAMP(k) do { } while (0)
+#endif
+
+    // one row's cross-wave size-2 stage after the trade: mine / partner's are out_H[k], point 2k = out_0 + out_1, point 2k+1 = out_0 + (-out_1)
+    auto cross_read = [&](bool odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
+        if (!odd) {
+#pragma unroll
+            for (int m = 0; m < R; m++) { re[m] = re[m] + lds_ld(&rb[ln + 64 * m]); im[m] = im[m] + lds_ld(&rb[G::XSLOTS + ln + 64 * m]); }
+        } else {
+#pragma unroll
+            for (int m = 0; m < R; m++) { re[m] = lds_ld(&rb[ln + 64 * m]) + (-re[m]); im[m] = lds_ld(&rb[G::XSLOTS + ln + 64 * m]) + (-im[m]); }
+        }
+    };
+    auto cross_write = [&](const double (&re)[R], const double (&im)[R], double* wb, int ln) {
+#pragma unroll
+        for (int m = 0; m < R; m++) { lds_st(&wb[ln + 64 * m], re[m]); lds_st(&wb[G::XSLOTS + ln + 64 * m], im[m]); }
+    };
+
+    // The whole step loop exists twice, once per parity, chosen ONCE (the waves of a workgroup meet at no barrier inside it): with the parity a
+    // compile-time constant each copy is straight-line code.  A wave-uniform branch on H around the few places that differ (the size-4 half
+    // stages, "mine + partner" against "partner + (-mine)") made the register allocator spill 232 of the 256 registers.
+    auto steps = [&](auto parity) {
+    constexpr bool ODD = decltype(parity)::value;
+#pragma unroll 1
+    for (int i = 0; i < a.steps; i++) {
+        const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
+        double s0re[R], s0im[R], s1re[R], s1im[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) { s0re[m] = 0.0; s0im[m] = 0.0; s1re[m] = 0.0; s1im[m] = 0.0; }
+
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t* poly = accbuf + h * N;
+            int ln = lane0;
+            asm volatile("" : "+v"(ln));        // keeps the lane-derived LDS addresses from being hoisted out of the loops and spilled
+            EO_STAMP(6);
+            // this lane's 8 complex inputs are points i = 2 (ln + 64 m) + H: coefficients i (real part) and i + 1024 (imaginary part)
+            // (rotate: math.rs:85-132; decomposition: math.rs:300-326; twist: spqlios-fft-impl.cpp:496-518)
+            cplx tH[R];        // twist factors from global memory: requested before the gather they land under
+#pragma unroll
+            for (int m = 0; m < R; m++) tH[m] = gtwist0[m * 64 + ln];
+            uint32_t ure[R], uim[R];
+            {
+                const int e0 = (2 * ln + H - r) * 4;                     // 4 (i - r) for m = 0; a lane's points are 512 bytes apart, re / im 4096
+                const unsigned char* pb = reinterpret_cast<const unsigned char*>(poly);
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const int c0 = 2 * (ln + 64 * m) + H, c1 = c0 + 1024;
+                    const int t0 = e0 + 512 * m, t1 = t0 + 4096;
+                    const uint32_t v0 = *reinterpret_cast<const uint32_t*>(pb + (t0 & (4 * N - 4)));
+                    const uint32_t v1 = *reinterpret_cast<const uint32_t*>(pb + (t1 & (4 * N - 4)));
+                    const uint32_t sg0 = (uint32_t)((int32_t)((uint32_t)t0 << (31 - LOGN - 2)) >> 31);     // all ones iff bit LOGN of (i - r) is set
+                    const uint32_t sg1 = (uint32_t)((int32_t)((uint32_t)t1 << (31 - LOGN - 2)) >> 31);
+                    ure[m] = ((((v0 ^ sg0) - sg0) - poly[c0]) + M) ^ M;
+                    uim[m] = ((((v1 ^ sg1) - sg1) - poly[c1]) + M) ^ M;
+                }
+            }
+            EO_STAMP(0);
+            double yr[L][R], yi[L][R];
+#pragma unroll
+            for (int jj = 0; jj < L; jj++)
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const double a0 = (double)decomp_digit(ure[m], BGBIT, jj), b0 = (double)decomp_digit(uim[m], BGBIT, jj);
+                    const double rc = a0 * tH[m].x, ic = b0 * tH[m].x, rs = a0 * tH[m].y, is = b0 * tH[m].y;
+                    yr[jj][m] = rc - is; yi[jj][m] = ic + rs;
+                }
+            // passes 1 and 2 of the three rows side by side (twiddles of this parity), both wave-private exchanges
+            {
+                Tw<R - 1> w1;
+                w1.load(tw_fwd12 + G::TW_P1 + ln, 64);
+#pragma unroll
+                for (int jj = 0; jj < L; jj++) {
+                    P12<R, G::LR - 1>::fwd(yr[jj], yi[jj], w1.w);
+                    exchange<10, 1, 2, true>(yr[jj], yi[jj], wbuf, ln);
+                }
+                Tw<R - 1> w2;
+                w2.load(tw_p2 + (ln & (G::NLOW - 1)), G::NLOW);
+#pragma unroll
+                for (int jj = 0; jj < L; jj++) {
+                    P12<R, G::LR - 1>::fwd(yr[jj], yi[jj], w2.w);
+                    exchange<10, 2, 3, true>(yr[jj], yi[jj], wbuf, ln);
+                }
+            }
+            EO_STAMP(1);
+            const int rc0 = h * 2 * L;                  // rc = 2 * row + comp
+            fetch(bA, i, rc0);                          // (row 0, c0): in flight under pass 3 and the trades
+            // pass 3 row by row; a row's values go to the partner right behind it and the NEXT row's pass 3 (for the last row: the first
+            // multiply-accumulates) runs between the arrival flag and the wait.  The buffers swap owners after every trade (ping-pong, see
+            // k_bootstrap_halves): row 0 is written to my buffer, row 1 to the one I read row 0 from, row 2 to the one I read row 1 from.
+            Tw<6> w3;
+            w3.load(tw_p3, 1);
+            auto pass3 = [&](int jj) { eo_fwd_pass3<R, ODD>(yr[jj], yi[jj], w3.w); };
+            pass3(0);
+            cross_write(yr[0], yi[0], wbuf, ln); EO_ARRIVE();
+            pass3(1);
+            EO_WAIT(); cross_read(ODD, yr[0], yi[0], rbuf, ln);
+            cross_write(yr[1], yi[1], rbuf, ln); EO_ARRIVE();
+            pass3(2);
+            EO_WAIT(); cross_read(ODD, yr[1], yi[1], wbuf, ln);
+            cross_write(yr[2], yi[2], wbuf, ln); EO_ARRIVE();
+            fetch(bB, i, rc0 + 1);                      // (row 0, c1): requested once pass 3's twiddles are dead (both buffers live through pass 3 spill)
+            EO_STAMP(2);
+            // hadamard + fold-add (spqlios.rs:204-222, trgsw.rs:290-299): this wave's parity of the points; each accumulator folds the
+            // polynomial's rows in order (and over the step: rows 0..5 in order); two key-row buffers, refilled as a multiply-accumulate retires
+            mac_row<R>(s0re, s0im, bA, yr[0], yi[0]); fetch(bA, i, rc0 + 2);           // (row 1, c0)
+            mac_row<R>(s1re, s1im, bB, yr[0], yi[0]); fetch(bB, i, rc0 + 3);           // (row 1, c1)
+            mac_row<R>(s0re, s0im, bA, yr[1], yi[1]); fetch(bA, i, rc0 + 4);           // (row 2, c0)
+            mac_row<R>(s1re, s1im, bB, yr[1], yi[1]); fetch(bB, i, rc0 + 5);           // (row 2, c1)
+            EO_WAIT(); cross_read(ODD, yr[2], yi[2], rbuf, ln);
+            { double* t = wbuf; wbuf = rbuf; rbuf = t; }        // three trades: I now own the buffer I read last
+            mac_row<R>(s0re, s0im, bA, yr[2], yi[2]);
+            mac_row<R>(s1re, s1im, bB, yr[2], yi[2]);
+            EO_STAMP(3);
+        }
+
+        // inverse: the size-2 stage across the waves comes FIRST (decimation in time), then this parity's sub-network, untwist, truncate, += acc
+#pragma unroll 1
+        for (int comp = 0; comp < 2; comp++) {
+            double re[R], im[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) { re[m] = comp ? s1re[m] : s0re[m]; im[m] = comp ? s1im[m] : s0im[m]; }
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            cross_write(re, im, wbuf, lane); EO_ARRIVE();
+            Tw<6> w3; Tw<R - 1> w2, w1; Tw<R> wt;
+            w1.load(gip10 + lane, 64);                  // global memory: requested first, used last
+#pragma unroll
+            for (int m = 0; m < R; m++) wt.w[m] = guntw0[m * 64 + lane];
+            w3.load(twi_p3, 1);
+            w2.load(twi_p2 + (lane & (G::NLOW - 1)), G::NLOW);
+            EO_WAIT(); cross_read(ODD, re, im, rbuf, lane);
+            { double* t = wbuf; wbuf = rbuf; rbuf = t; }
+            EO_STAMP(4);
+            eo_inv_pass3<R, ODD>(re, im, w3.w);
+            exchange<10, 3, 2, true>(re, im, wbuf, lane);
+            P12<R, G::LR - 1>::inv(re, im, w2.w);
+            exchange<10, 2, 1, true>(re, im, wbuf, lane);
+            P12<R, G::LR - 1>::inv(re, im, w1.w);
+            {
+                uint32_t* poly = accbuf + comp * N;
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const double vr = re[m], vi = im[m];
+                    // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395); the 2/N of fft_processor_spqlios.cpp:158 is in the table
+                    const double rc = vr * wt.w[m].x, ic = vi * wt.w[m].x, rs = vr * wt.w[m].y, is = vi * wt.w[m].y;
+                    const int c = 2 * (lane + 64 * m) + H;
+                    poly[c] += trunc_to_torus(rc - is);
+                    poly[c + P] += trunc_to_torus(ic + rs);
+                }
+            }
+            // (my accumulator words are published by my next arrival -- the other component's trade / the next step's first row -- which the
+            // partner waits for before it gathers them; see k_bootstrap_halves)
+            EO_STAMP(5);
+        }
+    }
+    };
+    if (H) steps(std::true_type{}); else steps(std::false_type{});
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();      // the last accumulator update has no arrival behind it: both parities' words must be visible below
+#ifdef RTFHE_WG_STAMPS
+    if (a.dbg && blockIdx.x == 0 && lane0 == 0)
+        for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];
+#endif
+
+    if (a.mode == MODE_BLIND_ROTATE) {
+        if (live) {
+            uint32_t* o = a.out + (size_t)g * 2 * N;
+            for (int c = lane0 + 64 * H; c < 2 * N; c += 128) o[c] = accbuf[c];
+        }
+        return;
+    }
+
+    // sample extract index 0 (trlwe.rs:110-121): a'_0 = a_0, a'_k = -a_{N-k}; b' = b_0
+    {
+        uint32_t av[2 * R];
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) av[mm] = accbuf[N + lane0 + 64 * mm + 1024 * H];
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 2 * R; mm++) {
+            const int c = lane0 + 64 * mm + 1024 * H;
+            accbuf[N + ((N - c) & (N - 1))] = (c == 0) ? av[mm] : (0u - av[mm]);
+        }
+    }
+    __syncthreads();
+    if (a.mode == MODE_EXTRACT) {      // the key switch of the whole batch follows as its own launch (k_key_switch_mm)
+        if (live) {
+            uint32_t* o = a.ext + (size_t)g * (N + 1);
+            for (int c = H * (N / 2) + lane0; c < (H + 1) * (N / 2); c += 64) o[c] = accbuf[N + c];
+            if (H == 0 && lane0 == 0) o[N] = accbuf[0];
+            for (int c = H * 64 + lane0; c <= n; c += 128) io.out[c] = 0u;
+        }
+        return;
+    }
+    // identity key switch (tlwe.rs:43-73): each wave sums the rows of half of the coefficients
+    uint4 sum[KSQ];
+    ks_accumulate<LOGN, KS_T, KS_BB, KSQ>(accbuf + N, H * (N / 2), (H + 1) * (N / 2), a.ksk, a.ksw, sum, lane0);
+    uint4* part = reinterpret_cast<uint4*>(xb1) + lane0;   // [KSQ][64] uint4
+    if (H == 1) {
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) part[q * 64] = sum[q];
+    }
+    __syncthreads();
+    if (H == 0 && live) {
+        const uint32_t bprime = accbuf[0];
+        uint32_t* out = io.out;
+#pragma unroll
+        for (int q = 0; q < KSQ; q++) {
+            const uint4 o = part[q * 64];
+            const int col = 4 * (lane0 + 64 * q);
+            const uint32_t s[4] = {sum[q].x + o.x, sum[q].y + o.y, sum[q].z + o.z, sum[q].w + o.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (col + e <= n) out[col + e] = ((col + e == n) ? bprime : 0u) - s[e];
+        }
+    }
+}
+
+}  // namespace rtfhe

@@ -292,7 +292,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #pragma unroll
             for (int m = 0; m < R; m++) tH[m] = gtwist[(8 * H + m) * 64];
             uint32_t ure[R], uim[R];
-#ifdef HALVES_GATHER2     // A/B: the rotated gather on byte offsets -- one add per coefficient from a per-polynomial base, mask, sign by xor / subtract
+#ifndef HALVES_GATHER1    // round 4: the rotated gather on byte offsets -- one add per coefficient from a per-polynomial base, mask, sign by xor / add: 9 instead of
+                          // 11 integer instructions per coefficient; 16.01 -> 15.82 ms per 1024 gates, 15.11 -> 14.91 per 768 (profiles/r04/n2048_variants_ab.log).
+                          // -DHALVES_GATHER1: rotated_coef() as in the other kernels
             {
                 const int e0 = (ln + 512 * H - r) * 4;                   // 4 (c - r) for m = 0; the coefficients of a lane are 256 m and 4096 bytes apart
                 const unsigned char* pb = reinterpret_cast<const unsigned char*>(poly);

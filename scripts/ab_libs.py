@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of several builds of librtfhe_hip.so in ONE process, interleaved rounds: prints per-build median/min launch time
-of a NAND batch and whether all outputs agree.  usage: ab_libs.py gates rounds lib1.so lib2.so ...  (RTFHE_FORCE_WAVES etc. apply to all)"""
+of a NAND batch and whether all outputs agree.  usage: ab_libs.py gates rounds lib1.so lib2.so ...  (RTFHE_FORCE_WAVES etc. apply to all;
+an argument of the form lib.so:KEY=VAL[:KEY2=VAL2] sets those environment variables around that build's context creation only)"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,12 @@ in0, in1 = R.encrypt_bits(P, key0, b0, 1), R.encrypt_bits(P, key0, b1, 2)
 d0 = torch.from_numpy(in0.view(np.int32)).cuda(); d1 = torch.from_numpy(in1.view(np.int32)).cuda()
 st = torch.cuda.current_stream().cuda_stream
 engines, outs = [], []
-for path in libs:
+names = []
+for spec in libs:
+    path, *envs = spec.split(":")
+    names.append(os.path.basename(path) + ("[" + ",".join(envs) + "]" if envs else ""))
+    for kv in envs:
+        os.environ[kv.split("=")[0]] = kv.split("=", 1)[1]
     L = C.CDLL(os.path.abspath(path))
     for name, (res, args) in _ffi._SIGNATURES.items():
         fn = getattr(L, name); fn.restype = res; fn.argtypes = [C.POINTER(R.Params) if a == "PP" else a for a in args]
@@ -30,6 +36,8 @@ for path in libs:
     if os.environ.get("RTFHE_BACKEND") == "ntt":
         e.set_backend(1)
     engines.append(e); outs.append(torch.empty_like(d0))
+    for kv in envs:
+        del os.environ[kv.split("=")[0]]
 times = [[] for _ in libs]
 for r in range(rounds + 1):
     for k, e in enumerate(engines):
@@ -40,5 +48,5 @@ for r in range(rounds + 1):
 same = all(bool(torch.equal(outs[0], o)) for o in outs[1:])
 for k, path in enumerate(libs):
     t = np.array(times[k])
-    print(json.dumps({"lib": os.path.basename(path), "gates": G, "median_ms": round(float(np.median(t)), 4), "min_ms": round(float(t.min()), 4),
+    print(json.dumps({"lib": names[k], "gates": G, "median_ms": round(float(np.median(t)), 4), "min_ms": round(float(t.min()), 4),
                       "gates_per_s_median": round(G / np.median(t) * 1e3, 1), "outputs_identical": same}), flush=True)

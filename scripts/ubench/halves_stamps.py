@@ -2,7 +2,9 @@
 """Diagnostic: per-phase time shares of the N = 2048 kernel (library built with -DRTFHE_WG_STAMPS into build/ab/stamps.so).
 Phases per CMUX step (summed over both polynomials / components): 0 gather + decomposition words | 1 first stage (own rows, trade with the
 partner half) | 2 sub-transforms of three rows | 3 multiply-accumulate with the key rows | 4 inverse sub-network | 5 last stage across the halves,
-untwist, accumulator update | 6 loop overhead / previous phase's tail."""
+untwist, accumulator update | 6 loop overhead / previous phase's tail.
+With RTFHE_N2048_KERNEL=eo (k_bootstrap_eo): 0 gather | 1 digits, twist, passes 1-2 of three rows with their exchanges | 2 pass 3 + the three row trades |
+3 multiply-accumulate (incl. the wait for the last row) | 4 inverse: trade of the sums + table loads | 5 inverse sub-network, untwist, update | 6 loop top."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

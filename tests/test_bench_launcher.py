@@ -111,6 +111,27 @@ def test_dp_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
     assert cvt == per_wave_cvt, (cvt, per_wave_cvt)
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_n2048_parity_split_kernel_executes_the_reference_operation_list(tmp_path):
+    """k_bootstrap_eo holds its step loop twice (one copy per parity, each with its polynomial loop and its component loop not unrolled): the
+    FP64-rate instructions of the two copies together are what the two waves of a gate execute per (polynomial + component) -- the reference's
+    operation list for N = 2048 (bench.dp_wave_instr_per_cmux: 8,256 per CMUX = 2 x 4,128) minus the unit-twiddle butterflies of the
+    even-point network (3 per transform x 6 instructions: one in the halfnn = 8 stage, two in the halfnn = 4 stage), and no v_fma_f64."""
+    import bench
+    from rustfhe_amd import build as b
+    asm = tmp_path / "api.s"
+    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + \
+          ["--cuda-device-only", "-S", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"), "-o", str(asm)]
+    subprocess.check_call(cmd)
+    m = re.search(r"\n(_ZN5rtfhe14k_bootstrap_eoILi3ELi6ELi8ELi2ELi3ELi4E\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm.read_text(), re.S)
+    assert m, "k_bootstrap_eo not found in the device assembly"
+    f64 = len(re.findall(r"^\s*v_(?:add|mul|cvt_f64_i32|trunc)_f64|^\s*v_cvt_f64_i32|^\s*v_trunc_f64", m.group(2), re.M))
+    assert len(re.findall(r"^\s*v_fma_f64", m.group(2), re.M)) == 0
+    ref = bench.dp_wave_instr_per_cmux(2048, 3)["reference"]
+    # static = (one polynomial + one component) per parity = half a CMUX step per parity; the even parity saves 18 per transform, 4 transforms in it
+    assert f64 == ref // 2 - 4 * 18, (f64, ref)
+
+
 def test_ntt_opcount_formula():
     import bench
     o = bench.ntt_dp_wave_instr_per_cmux(1024, 3)

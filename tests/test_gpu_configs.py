@@ -278,17 +278,22 @@ def test_key_file_feeds_an_engine(tmp_path, params, keys, gold_gate):
     e.close()
 
 
-def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch):
-    """N = 2048: the two-waves-per-transform kernel (default) and the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4) are the
-    same arithmetic: identical words for a ragged batch, and for blind-rotate prefixes (both compared with the oracle above)."""
+@pytest.mark.parametrize("other", ["one_wave_per_gate", "top_bit_split", "parity_split"])
+def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch, other):
+    """N = 2048: the default dispatch (two waves per transform: split by the parity of the point index, k_bootstrap_eo, at 1-2 gates per
+    workgroup; by the top index bit, k_bootstrap_halves, at 3-4) against the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4) and against each
+    split forced for every shape (RTFHE_N2048_KERNEL) -- the same arithmetic: identical words for a ragged batch, for blind-rotate prefixes
+    (both compared with the oracle above) and for every launch shape."""
     import rustfhe_amd as R
     P, K, e = setup2048
     rng = np.random.default_rng(2048)
     b0, b1 = rng.integers(0, 2, 37), rng.integers(0, 2, 37)
     c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
-    monkeypatch.setenv("RTFHE_FORCE_WAVES", "4")
+    knob, val = {"one_wave_per_gate": ("RTFHE_FORCE_WAVES", "4"), "top_bit_split": ("RTFHE_N2048_KERNEL", "halves"),
+                 "parity_split": ("RTFHE_N2048_KERNEL", "eo")}[other]
+    monkeypatch.setenv(knob, val)
     one = R.Engine(R.Params(N=2048), 0)
-    monkeypatch.delenv("RTFHE_FORCE_WAVES")
+    monkeypatch.delenv(knob)
     try:
         one.load_bk_torus(K.bk_t)
         one.load_ksk(K.ksk)
@@ -299,10 +304,10 @@ def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch):
             assert np.array_equal(e.blind_rotate_batch(t, steps), one.blind_rotate_batch(t, steps))
         assert K.decrypt_bits(e.gate_batch(R.NAND, c0, c1)) == list(1 - (b0 & b1))
         # launch shapes by batch size (1, 2, 3 gates per workgroup below a full round): the same words as one wave per gate
-        bb0, bb1 = rng.integers(0, 2, 600), rng.integers(0, 2, 600)
+        bb0, bb1 = rng.integers(0, 2, 1030), rng.integers(0, 2, 1030)
         d0, d1 = K.encrypt_bits(bb0), K.encrypt_bits(bb1)
         ref = one.gate_batch(R.NAND, d0, d1)
-        for k in (257, 600):
+        for k in (257, 513, 770, 1030):
             assert np.array_equal(e.gate_batch(R.NAND, d0[:k], d1[:k]), ref[:k]), k
     finally:
         one.close()
