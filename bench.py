@@ -189,6 +189,13 @@ def launch(args):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only): the oracle / the reference's own FFT on the host cores.  Checker, never product.
 # ------------------------------------------------------------------------------------------------------------------
+def under_profiler():
+    """rocprofv3 preloads its tool library into the program it starts, and that library may initialise the GPU before main(): a process
+    in that state must not start other programs (this pool refuses the exec).  Under the profiler bench.py therefore measures in THIS process:
+    no supervisor, no CPU-baseline child (the baseline is not what a profile is taken for)."""
+    return "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCPROFILER_LIBRARY_CTOR"))
+
+
 def _signal_name(rc):
     import signal
     if rc is None or rc >= 0:
@@ -549,6 +556,8 @@ def cargo_probe():
     if not cargo:
         return "absent"
     res = {"cargo": cargo}
+    if under_profiler():
+        return res
     try:
         res["version"] = subprocess.run([cargo, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
         crate = os.path.join(ROOT, "bindings", "rust", "rtfhe-sys")
@@ -598,8 +607,9 @@ def run_rank(args):
         key0, key1, bk, ksk = R.keygen(params, 20211003)
     else:
         key0, bk, ksk = np.empty(params.n, np.int32), np.empty(params.bk_words, np.uint32), np.empty(params.ksk_words, np.uint32)
+    cargo_info = cargo_probe() if rank == 0 else None      # (may start `cargo`: before this process touches the GPU, like the child below)
     cpu_child = None
-    want_cpu = world == 1 and not args.no_cpu_baseline and mirror and not config3
+    want_cpu = world == 1 and not args.no_cpu_baseline and mirror and not config3 and not under_profiler()
     if want_cpu:
         rng = np.random.default_rng(1000 + rank)
         b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
@@ -828,7 +838,7 @@ def run_rank(args):
         # The headline above is complete at this point, and nothing below may cost it.  Under supervise() (plain `python bench.py`, N = 1) the
         # line goes out NOW, marked provisional, and again after every side leg: if this process then dies of a native crash in a side
         # kernel or library, the supervisor prints the last line it saw and exits 0.  The CPU baseline runs in a process of its own.
-        line["cargo"] = cargo_probe()
+        line["cargo"] = cargo_info
         pending = []
         if isinstance(cpu_child, (CpuBaselineChild, dict)):
             pending.append("cpu_baseline")
@@ -888,7 +898,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args))                      # parent: spawn the ranks, never touch the GPU
-    if "WORLD_SIZE" not in os.environ and not os.environ.get("RTFHE_BENCH_INNER"):
+    if "WORLD_SIZE" not in os.environ and not os.environ.get("RTFHE_BENCH_INNER") and not under_profiler():
         # N = 1, started by hand or by the driver: this process only supervises (never imports torch, never touches the GPU)
         sys.exit(supervise([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:

@@ -261,6 +261,7 @@ struct rtfhe_ctx {
     cplx* d_hbk = nullptr;            // N = 2048: key spectra in the halves layout
     cplx* d_etw = nullptr;            // N = 2048: tables of k_bootstrap_eo
     cplx* d_ebk = nullptr;            // N = 2048: key spectra in the even / odd layout
+    unsigned long long tune = 0;      // tuning builds only (rtfhe_debug_set_tune): handed to the kernels as BootstrapArgs::tune
     int n2048_kernel = -1;            // -1 = by launch shape (below), 0 = parity split (k_bootstrap_eo), 1 = top-bit split (k_bootstrap_halves);
                                       // RTFHE_N2048_KERNEL=eo|halves
     int backend = RTFHE_BACKEND_FFT64_MIRROR;
@@ -777,6 +778,7 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     a.ops = d_ops; a.idx0 = d_idx0; a.idx1 = d_idx1; a.idx_out = d_idx_out;
     a.num_wires = num_wires; a.fault = ctx->d_fault;
     a.dbg = ctx->d_dbg;
+    a.tune = ctx->tune;
     a.ext = nullptr;
     struct Unset { bool& f; ~Unset() { f = false; } } unset{ctx->foreign_capture};
     if (mode == MODE_GATE && ctx->ks_mm_min > 0 && ctx->d_ksmat && !ctx->tlwe1_capture) {
@@ -1165,6 +1167,13 @@ void* rtfhe_host_alloc(size_t bytes) {
     return p;
 }
 void rtfhe_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// tuning builds only (-DPAIR_PRIO_RUNTIME / -DHALVES_PRIO_RUNTIME): the priority schedule the next launches try (scripts/tune_prio.py)
+extern "C" int rtfhe_debug_set_tune(rtfhe_ctx* ctx, unsigned long long tune) {
+    if (!ctx) return RTFHE_ERR_INVALID;
+    ctx->tune = tune;
+    return 0;
+}
 
 #ifdef RTFHE_WG_STAMPS
 extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out128) {

@@ -439,9 +439,7 @@ struct XAffine {
 };
 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// P1DONE: the first P1DONE rows arrive with pass 1 already applied (a caller that had arithmetic-free time to fill -- the N = 2048 kernel's wait for
-// its partner's last traded row -- ran P12<R, LR - 1>::fwd on them with the pass-1 twiddles itself)
-template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook, bool INTERLEAVE = false, int P1DONE = 0>
+template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook, bool INTERLEAVE = false>
 __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
                                                     const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane,
                                                     HOOK after_pass1 = HOOK()) {
@@ -462,7 +460,6 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
                 im[j][k] = ic + rs;
             }
     }
-  static_assert(!(INTERLEAVE && P1DONE), "P1DONE is wired for the plain form only");
   if constexpr (INTERLEAVE) {
     // Interleaved form (N = 1024, R = 8): a row's 16 exchange writes follow its pass; its 16 reads are issued in two groups of 8 BETWEEN the three
     // stages of the NEXT row's pass (the last row's between the stages of the next pass's first row), each group pinned by scheduling barriers.  No
@@ -510,7 +507,7 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
         w1.load(tw + G::TW_P1 + lane, 64);
 #pragma unroll
         for (int j = 0; j < NR; j++) {
-            if (j >= P1DONE) P12<R, G::LR - 1>::fwd(re[j], im[j], w1.w);
+            P12<R, G::LR - 1>::fwd(re[j], im[j], w1.w);
             exchange<LOGN, 1, 2, true>(re[j], im[j], xbuf, lane, xim);
         }
     }

@@ -43,6 +43,7 @@ struct BootstrapArgs {
     int32_t num_wires;       // netlist mode: rows in the wire table; indices and opcodes are checked against it on the device
     int32_t* fault;          // netlist mode: set to 1 when a gate was skipped for an out-of-range index / unknown opcode
     unsigned long long* dbg;   // diagnostic builds only (RTFHE_WG_STAMPS): per-phase cycle sums of workgroup 0
+    unsigned long long tune;   // tuning builds only (-DPAIR_PRIO_RUNTIME, scripts/tune_prio.py): a priority schedule to try, 3 bits per (side, point)
 };
 
 // gate pre-step on one TLWE word (a-part: isb = false, b-part: isb = true), hom_nand/src/tfhe.rs:27-71

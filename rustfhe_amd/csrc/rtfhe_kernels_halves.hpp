@@ -46,6 +46,12 @@
 #ifndef HALVES_EARLY_ROW
 #define HALVES_EARLY_ROW 1
 #endif
+#ifndef HALVES_STAIRS
+#define HALVES_STAIRS 2     // 2: pass 1 at priority 3, pass 2 at 2, pass 3 at 1, multiply-accumulate at 0 (16.13 -> 16.06 ms per 1024 gates, 14.12 -> 13.98 per 768); 1: coarser; 0: off
+#endif
+#ifndef HALVES_OPAQUE_WAIT
+#define HALVES_OPAQUE_WAIT 1
+#endif
 #ifndef HALVES_SPLIT_MIN
 #define HALVES_SPLIT_MIN 3   // gates per workgroup from which the two halves trade the first stage's inputs instead of both computing all of them
 #endif
@@ -169,10 +175,19 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
 #define HALVES_SYNC() pair_sync(my_flag, partner_flag, ++sync_k)
 #endif
 #define HALVES_ARRIVE() pair_arrive(my_flag, ++sync_k)
-#ifdef HALVES_OPAQUE_WAIT      // A/B: the spin loop inside one inline-assembly statement (no loop header in the compiler's control-flow graph)
-#define HALVES_WAIT() pair_wait_opaque(partner_flag, sync_k)
+    // The priority staircase of k_bootstrap_eo (round 4): a wave's priority falls along every stretch between two trades and is back at 3 after
+    // every wait, so that whichever half is BEHIND is favoured (round 3: half B at a fixed higher priority -- it raced to every trade and idled
+    // there a quarter of the step).  With the opaque wait: 1024 gates 15.66 -> 15.52 ms, 768 gates 14.94 -> 14.05 ms (profiles/r04/
+    // n2048_priority_staircase_ab.log).  -DHALVES_STAIRS=0 -DHALVES_OPAQUE_WAIT=0: round 3's form.
+#if HALVES_STAIRS
+#define HV_PRIO(k) __builtin_amdgcn_s_setprio(k)
 #else
-#define HALVES_WAIT() pair_wait(partner_flag, sync_k)
+#define HV_PRIO(k) do { } while (0)
+#endif
+#if HALVES_OPAQUE_WAIT      // the spin loop inside one inline-assembly statement (no loop header in the compiler's control-flow graph)
+#define HALVES_WAIT() do { pair_wait_opaque(partner_flag, sync_k); HV_PRIO(3); } while (0)
+#else
+#define HALVES_WAIT() do { pair_wait(partner_flag, sync_k); HV_PRIO(3); } while (0)
 #endif
 #ifdef HALVES_ABL_NOSYNC       // timing ablation only (racy, wrong results)
 #undef HALVES_SYNC
@@ -238,7 +253,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+#if !HALVES_STAIRS
     if (H) __builtin_amdgcn_s_setprio(HALVES_PRIO_B);
+#endif
     // Priority schedule of wave B: after point p it runs at priority 0 if bit p of HALVES_B_LOW_MASK is set, at HALVES_PRIO_B otherwise (wave A stays at 0; at
     // equal priority the SIMD favours the older wave, A).  Points: 0 start of a polynomial, 1 after the first stage, 2 after passes 1-2 of the sub-transforms,
     // 3 after pass 3, 4 after the multiply-accumulate, 5 after an inverse sub-network, 6 after the last stage + accumulator update
@@ -343,14 +360,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 for (int m = 0; m < R; m++) { lds_st(&wb[ln + 64 * m], xr[m]); lds_st(&wb[G::XSLOTS + ln + 64 * m], xi[m]); }
                 HALVES_ARRIVE();
                 if (HALVES_EARLY_ROW && jj + 1 < L) own_row2(jj + 1);
-#ifdef HALVES_EARLY_PASS1     // A/B: the last row's wait has no own products left to cover it: pass 1 of the sub-transforms of rows 0, 1 goes there
-                if (jj == L - 1) {
-                    Tw<R - 1> w1e;
-                    w1e.load(tw_sub + G::TW_P1 + ln, 64);
-#pragma unroll
-                    for (int j2 = 0; j2 < L - 1; j2++) P12<R, G::LR - 1>::fwd(yr[j2], yi[j2], w1e.w);
-                }
-#endif
                 HALVES_WAIT();
                 if (H == 0) {                           // mine = x0, partner's = x1
 #pragma unroll
@@ -452,13 +461,15 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             HV_STAMP(1);
             prio_point(1);
             // the 512-point sub-transforms of the three rows side by side
-#ifdef HALVES_EARLY_PASS1
-            if constexpr (SPLIT1 && PINGPONG) fft_forward_multi_a<10, L, false, NoHook, false, L - 1>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
-            else fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
+#if HALVES_STAIRS == 2     // the finer staircase: pass 1 at 3, pass 2 at 2, pass 3 at 1, multiply-accumulate at 0
+            auto step_down = [&]() { HV_PRIO(2); };
+            fft_forward_multi_a<10, L, false, decltype(step_down)>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln, step_down);
 #else
+            HV_PRIO(2);
             fft_forward_multi_a<10, L, false>(yr, yi, tw_sub, wbuf, wbuf + G::XSLOTS, ln);
 #endif
             prio_point(2);
+            HV_PRIO(1);
 #ifndef HALVES_FETCH_LATE
             fetch(bA, i, h * 2 * L);                    // (row 0, comp 0) of this polynomial: in flight under the last pass
 #endif
@@ -471,6 +482,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
             // each refilled as soon as its multiply-accumulate has retired
             HV_STAMP(2);
             prio_point(3);
+            HV_PRIO(0);
             const int rc0 = h * 2 * L;                  // rc = 2 * row + comp
             fetch(bB, i, rc0 + 2);                                                     // (row 1, c0)
             mac_row<R>(s0re, s0im, bA, yr[0], yi[0]); fetch(bA, i, rc0 + 4);           // (row 2, c0)
@@ -499,8 +511,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_halves(const Halve
                 P3<R, G::NLOW, G::LOW - 1, BOOT_TRIV>::template inv<false>(re, im, w3.w);
                 w2.load(twi_small + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
                 exchange<10, 3, 2, true>(re, im, wbuf, lane);
+                HV_PRIO(2);
                 P12<R, G::LR - 1>::inv(re, im, w2.w);
                 exchange<10, 2, 1, true>(re, im, wbuf, lane);
+                HV_PRIO(1);
                 if constexpr (IST_EARLY) {
                     if (H == 1) {   // requested under the last pass
 #pragma unroll

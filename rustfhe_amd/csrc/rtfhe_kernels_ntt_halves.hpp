@@ -75,9 +75,17 @@ template <int L, int BGBIT, bool CMUX, bool PAIRSYNC = false>
 __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const __amdgpu_buffer_rsrc_t bk_rsrc, int bk_off,
                                                 const NttHalvesTables& t, double* myx, const double* otx,      /* the partner writes otx: no restrict */
                                                 int lane0, int H, unsigned my_flag = 0, unsigned partner_flag = 0, unsigned* sync_k = nullptr) {
+    // -DNTTH_STAIRS (A/B): the priority staircase of the FFT kernels at N = 2048 -- priority 3 after every synchronisation, falling row by row
+    // through the forward transforms, so that whichever half is behind is favoured
+#ifdef NTTH_STAIRS
+#define NTTH_PRIO(k) __builtin_amdgcn_s_setprio(k)
+#else
+#define NTTH_PRIO(k) do { } while (0)
+#endif
     auto halves_sync = [&]() {
         if constexpr (PAIRSYNC) pair_sync(my_flag, partner_flag, ++*sync_k);
         else lds_barrier();
+        NTTH_PRIO(3);
     };
     constexpr int LOGN = 11, N = 2048, HN = 1024, R = ntt::R;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
@@ -110,6 +118,7 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
             double x[R];
+            if (jj == 0) NTTH_PRIO(2); else if (jj == 1) NTTH_PRIO(1); else NTTH_PRIO(0);
             if (H) {        // branch on the half around the loop (a select inside it computes both sums)
 #pragma unroll
                 for (int m = 0; m < R; m++)

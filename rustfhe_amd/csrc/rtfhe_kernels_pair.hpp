@@ -274,6 +274,26 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #ifdef PAIR_FLAT_PRIO    // A/B: no schedule, every wave at priority 1
         return;
 #endif
+#ifdef PAIR_PRIO_RUNTIME  // tuning build (scripts/tune_prio.py): the schedule comes in a.tune, 3 bits per (side, point): 0..3 = s_setprio that level, 4..7 = leave
+        {
+            constexpr int slot_of[11] = {-1, 1, 2, -1, -1, 3, 4, 5, 6, 7, 0};     // points 10, 1, 2, 5, 6, 7, 8, 9 -> slots 0..7
+            if (slot_of[point] < 0) return;
+            const unsigned f = (unsigned)(a.tune >> (3 * (side * 8 + slot_of[point]))) & 7u;
+            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc0 1f\n\ts_setprio 0\n1:\n\t"
+                         "s_cmp_eq_u32 %0, 1\n\ts_cbranch_scc0 2f\n\ts_setprio 1\n2:\n\t"
+                         "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc0 3f\n\ts_setprio 2\n3:\n\t"
+                         "s_cmp_eq_u32 %0, 3\n\ts_cbranch_scc0 4f\n\ts_setprio 3\n4:" ::"s"(f) : "scc");
+            return;
+        }
+#endif
+#ifdef PAIR_STAIRS       // A/B: the symmetric priority staircase of the N = 2048 kernels -- both sides' priority falls 3 -> 0 along the stretch from
+                         // barrier 2 to barrier 1 (inverse + update | gather + pass 1 | pass 2 | pass 3 + slot P) and is 3 through slot Q
+        if (point == 9 || point == 7) asm volatile("s_setprio 3");
+        if (point == 10) asm volatile("s_setprio 2");
+        if (point == 1) asm volatile("s_setprio 1");
+        if (point == 2) asm volatile("s_setprio 0");
+        return;
+#endif
 #ifdef PAIR_MID_AT
         if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
 #else
@@ -292,6 +312,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     __builtin_amdgcn_s_setprio(1);
 #else
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#endif
+#ifdef PAIR_PRIO_RUNTIME
+    prio_point(10);
 #endif
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
