@@ -248,8 +248,6 @@ def cpu_baseline_child(tmpdir, per_thread):
     single = min(in_count, 16)
     target_s = float(os.environ.get("RTFHE_BENCH_CPU_TARGET_S", "2.5"))      # seconds an all-core run lasts at perfect scaling (tests shorten it)
 
-    cpu_sets = {}
-
     def leg(backend):
         # single thread first, on an otherwise idle host (after an all-core run the package is still clocked down)
         out1, s1 = orc.gate_batch_mt_numa(p, orc.NAND, bk_f, ksk, in0[:single], in1[:single], single, per_core[:1], topo["node_of"], backend=backend)
@@ -279,7 +277,6 @@ def cpu_baseline_child(tmpdir, per_thread):
             ok = ok and same
             ncores = len(set(topo["core_of"][c] for c in cpus))       # physical cores the threads occupy
             entitled = min(ncores, quota) if quota else ncores         # ... and the CPU time the cgroup lets them have
-            cpu_sets[name] = cpus
             runs.append({"threads": name, "threads_used": len(cpus), "pinned": pin, "gates": count, "gates_per_thread": k, "seconds": round(secs, 3),
                          "gates_per_s": round(count / secs, 1), "cores_busy": ncores, "cores_entitled": entitled,
                          "scaling_efficiency": round(count / secs / (entitled * rate1), 3), "matches_gpu_bit_exact": same})
@@ -313,16 +310,6 @@ def cpu_baseline_child(tmpdir, per_thread):
                "port": port}
         rate1, best = rate1r, best_r
     res["host"] = host
-    # the bound the all-core figure sits under: every gate streams the key spectra and the touched key-switching rows from memory
-    try:
-        cpus = cpu_sets[best["threads"]]                   # the threads of the run of record
-        bw = orc.stream_read_bandwidth(cpus, 128 << 20, 2)
-        res["memory"] = {"stream_read_GBps": round(bw / 1e9, 1), "bytes_per_gate": ALG_BYTES_PER_GATE,
-                         "gates_per_s_at_that_bandwidth": round(bw / ALG_BYTES_PER_GATE, 1),
-                         "note": "sustained read bandwidth of %d pinned threads over private 128 MiB buffers; a gate streams %.1f MB of keys, so the "
-                                 "all-core rate cannot exceed bandwidth / bytes per gate whatever the core count" % (len(cpus), ALG_BYTES_PER_GATE / 1e6)}
-    except Exception as e:          # noqa: BLE001
-        res["memory"] = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps(res), flush=True)
     return 0
 

@@ -54,6 +54,8 @@ extern "C" {
     pub fn rtfhe_ctx_params(ctx: *const rtfhe_ctx, p: *mut rtfhe_params) -> c_int;
     pub fn rtfhe_twiddles_load(ctx: *mut rtfhe_ctx, path: *const c_char, entries_changed: *mut i32) -> c_int;
     pub fn rtfhe_twiddles_write(ctx: *const rtfhe_ctx, path: *const c_char) -> c_int;
+    pub fn rtfhe_twiddles_file_write(path: *const c_char, n: i32, ifft_table: *const f64, fft_table: *const f64) -> c_int;
+    pub fn rtfhe_twiddles_file_read(path: *const c_char, n: i32, ifft_table: *mut f64, fft_table: *mut f64) -> c_int;
 
     pub fn rtfhe_load_bk_torus(ctx: *mut rtfhe_ctx, bk: *const u32) -> c_int;
     pub fn rtfhe_load_bk_fft(ctx: *mut rtfhe_ctx, bk_f: *const f64) -> c_int;

@@ -134,6 +134,9 @@ int rtfhe_ctx_params(const rtfhe_ctx *ctx, rtfhe_params *p);     /* the paramete
  * the tables of the reference build the golden vectors under tests/golden/ were made with. */
 int rtfhe_twiddles_load(rtfhe_ctx *ctx, const char *path, int32_t *entries_changed);
 int rtfhe_twiddles_write(const rtfhe_ctx *ctx, const char *path);
+/* the same file format without a context (pure file I/O, checksum verified on read): N = ring degree, 2N doubles per table */
+int rtfhe_twiddles_file_write(const char *path, int32_t N, const double *ifft_table, const double *fft_table);
+int rtfhe_twiddles_file_read(const char *path, int32_t N, double *ifft_table, double *fft_table);
 
 /* ---- keys ---- */
 int rtfhe_load_bk_torus(rtfhe_ctx *ctx, const uint32_t *bk /* [n][2][2l][N] */);

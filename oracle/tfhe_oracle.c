@@ -719,56 +719,6 @@ double orc_gate_batch_mt_numa(const orc_params *p, int backend, int op, const do
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
-/* Sustained read bandwidth of the host, for the one sentence bench.py writes next to the all-core figure: every gate streams the whole
- * 62 MB of key spectra and ~16 MB of key-switching rows, so the all-core CPU rate is bounded by (read bandwidth) / (78 MB per gate).
- * Each of nthreads threads (pinned like the baseline's) sums a private buffer of `bytes` bytes, first-touched by itself, `passes` times.
- * Returns bytes per second over all threads (from the moment every buffer is filled to the last thread's last pass); <= 0 on failure. */
-typedef struct { size_t bytes; int passes, cpu; pthread_barrier_t *ready; double sink; int fail; } bw_job;
-static void *bw_worker(void *arg) {
-    bw_job *j = (bw_job *)arg;
-    if (j->cpu >= 0) {
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        CPU_SET(j->cpu, &set);
-        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
-    }
-    const size_t n = j->bytes / sizeof(double);
-    double *buf = (double *)malloc(n * sizeof(double));
-    if (!buf) j->fail = 1;
-    else for (size_t i = 0; i < n; i++) buf[i] = (double)(i & 1023);
-    pthread_barrier_wait(j->ready);
-    if (buf) {
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int pass = 0; pass < j->passes; pass++)
-            for (size_t i = 0; i + 4 <= n; i += 4) { a0 += buf[i]; a1 += buf[i + 1]; a2 += buf[i + 2]; a3 += buf[i + 3]; }
-        j->sink = a0 + a1 + a2 + a3;
-        free(buf);
-    }
-    return NULL;
-}
-double orc_stream_read_mt(size_t bytes_per_thread, int passes, int nthreads, const int *cpus) {
-    if (nthreads < 1 || passes < 1) return -1.0;
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-    bw_job *jobs = (bw_job *)malloc(sizeof(bw_job) * (size_t)nthreads);
-    pthread_barrier_t ready;
-    pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1u);
-    struct timespec t0, t1;
-    for (int t = 0; t < nthreads; t++) {
-        jobs[t] = (bw_job){bytes_per_thread, passes, cpus ? cpus[t] : -1, &ready, 0.0, 0};
-        pthread_create(&th[t], NULL, bw_worker, &jobs[t]);
-    }
-    pthread_barrier_wait(&ready);
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    int fail = 0;
-    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); fail |= jobs[t].fail; }
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    pthread_barrier_destroy(&ready);
-    free(th); free(jobs);
-    if (fail) return -1.0;
-    const double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-    return secs > 0 ? (double)bytes_per_thread * passes * nthreads / secs : -1.0;
-}
-
 /* ================================================================= keys / encryption */
 
 static uint64_t splitmix64(uint64_t *x) {

@@ -137,9 +137,6 @@ double orc_gate_batch_mt_numa(const orc_params *p, int backend, int op, const do
                               const uint32_t *in0, const uint32_t *in1, size_t in_count, uint32_t *out, size_t count,
                               int nthreads, const int *cpus, const int *node_of_thread, int nnodes);
 
-/* sustained read bandwidth of the host in bytes per second (each thread sums a private, self-first-touched buffer `passes` times) */
-double orc_stream_read_mt(size_t bytes_per_thread, int passes, int nthreads, const int *cpus);
-
 /* ---------------------------------------------------------------- keys / encryption (own seeded RNG) */
 typedef struct { uint64_t s[4]; } orc_rng;
 void orc_rng_seed(orc_rng *r, uint64_t seed);

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "rtfhe_ctx_params": (C.c_int, [C.c_void_p, "PP"]),
     "rtfhe_twiddles_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "rtfhe_twiddles_write": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rtfhe_twiddles_file_write": (C.c_int, [C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rtfhe_twiddles_file_read": (C.c_int, [C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rtfhe_load_bk_torus": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_load_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtfhe_export_bk_fft": (C.c_int, [C.c_void_p, C.c_void_p]),

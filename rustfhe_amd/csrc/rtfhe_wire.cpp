@@ -117,49 +117,32 @@ int rtfhe_tlwe_read(const char* path, int32_t* n, uint64_t* count, uint32_t* cts
 }
 
 
-// Twiddle tables as a file (the tables are libm-dependent DATA -- cos / sin of a double-rounded angle; two hosts' libms may
-// differ by an ulp in a few entries, and one differing entry changes torus words).  A deployment that must reproduce a given reference
-// build's bits ships that build's tables and loads them here; rustfhe_amd/assets/ holds the tables of the reference build the golden
-// vectors were made with.  rtfhe_twiddles_write: the context's current tables.  rtfhe_twiddles_load: compares the file's tables with the
-// context's (built with this host's libm at rtfhe_ctx_create) and, only if they differ, installs the file's (rtfhe_set_twiddles: a key
-// loaded in torus form is re-transformed).  *entries_changed = table entries that differed (0: this host's libm agrees, nothing was done).
-int rtfhe_twiddles_write(const rtfhe_ctx* ctx, const char* path) {
-    if (!ctx || !path) return RTFHE_ERR_INVALID;
-    rtfhe_params p;
-    if (rtfhe_ctx_params(ctx, &p) != 0) return RTFHE_ERR_INVALID;
-    std::vector<double> t((size_t)4 * p.N);
-    if (int rc = rtfhe_get_twiddles(ctx, t.data(), t.data() + (size_t)2 * p.N)) return rc;
+// Twiddle tables as a file: pure file I/O here (the context-level rtfhe_twiddles_load / _write that compare and install live in rtfhe_api.hip).
+// N = the ring degree; ifft_table / fft_table: 2N doubles each, the reference's memory layout.  Read verifies magic, degree and checksum.
+int rtfhe_twiddles_file_write(const char* path, int32_t N, const double* ifft_table, const double* fft_table) {
+    if (!path || N < 16 || N > (1 << 20) || !ifft_table || !fft_table) return RTFHE_ERR_INVALID;
     FILE* f = std::fopen(path, "wb");
     if (!f) return RTFHE_ERR_INVALID;
-    Fnv h; const int32_t n = p.N, reserved = 0;
-    bool ok = wr(f, h, TW_MAGIC, 8) && wr(f, h, &n, 4) && wr(f, h, &reserved, 4) && wr(f, h, t.data(), t.size() * sizeof(double));
+    Fnv h; const int32_t reserved = 0;
+    bool ok = wr(f, h, TW_MAGIC, 8) && wr(f, h, &N, 4) && wr(f, h, &reserved, 4) && wr(f, h, ifft_table, (size_t)2 * N * sizeof(double)) &&
+              wr(f, h, fft_table, (size_t)2 * N * sizeof(double));
     const uint64_t sum = h.h;
     ok = ok && std::fwrite(&sum, 1, 8, f) == 8;
     ok = (std::fclose(f) == 0) && ok;
     return ok ? 0 : RTFHE_ERR_INVALID;
 }
 
-int rtfhe_twiddles_load(rtfhe_ctx* ctx, const char* path, int32_t* entries_changed) {
-    if (!ctx || !path) return RTFHE_ERR_INVALID;
-    if (entries_changed) *entries_changed = 0;
-    rtfhe_params p;
-    if (rtfhe_ctx_params(ctx, &p) != 0) return RTFHE_ERR_INVALID;
+int rtfhe_twiddles_file_read(const char* path, int32_t N, double* ifft_table, double* fft_table) {
+    if (!path || N < 16 || N > (1 << 20) || !ifft_table || !fft_table) return RTFHE_ERR_INVALID;
     FILE* f = std::fopen(path, "rb");
     if (!f) return RTFHE_ERR_INVALID;
     Fnv h; char magic[8]; int32_t n = 0, reserved = 0;
-    std::vector<double> t((size_t)4 * p.N), cur((size_t)4 * p.N);
-    bool ok = rd(f, h, magic, 8) && !std::memcmp(magic, TW_MAGIC, 8) && rd(f, h, &n, 4) && rd(f, h, &reserved, 4) && n == p.N &&
-              rd(f, h, t.data(), t.size() * sizeof(double));
+    bool ok = rd(f, h, magic, 8) && !std::memcmp(magic, TW_MAGIC, 8) && rd(f, h, &n, 4) && rd(f, h, &reserved, 4) && n == N &&
+              rd(f, h, ifft_table, (size_t)2 * N * sizeof(double)) && rd(f, h, fft_table, (size_t)2 * N * sizeof(double));
     uint64_t sum = 0;
     ok = ok && std::fread(&sum, 1, 8, f) == 8 && sum == h.h;
     std::fclose(f);
-    if (!ok) return RTFHE_ERR_INVALID;
-    if (int rc = rtfhe_get_twiddles(ctx, cur.data(), cur.data() + (size_t)2 * p.N)) return rc;
-    int32_t diff = 0;
-    for (size_t i = 0; i < t.size(); i++) diff += std::memcmp(&t[i], &cur[i], sizeof(double)) != 0;     // bits, not values: -0.0 vs +0.0 counts
-    if (entries_changed) *entries_changed = diff;
-    if (diff == 0) return 0;
-    return rtfhe_set_twiddles(ctx, t.data(), t.data() + (size_t)2 * p.N);
+    return ok ? 0 : RTFHE_ERR_INVALID;
 }
 
 }  // extern "C"

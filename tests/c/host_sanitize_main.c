@@ -65,6 +65,23 @@ int main(int argc, char **argv) {
         CHECK(rtfhe_tlwe_read(path2, &n, &count, ct2, CNT) != 0);
         CHECK(rtfhe_tlwe_read("/nonexistent/dir/x.bin", &n, &count, NULL, 0) != 0);
     }
+    {   /* twiddle table files (the table-file format of rtfhe_wire.cpp): round trip, wrong degree, corruption, truncation */
+        char path3[512];
+        snprintf(path3, sizeof path3, "%s/tw.bin", dir);
+        const int32_t TN = 64;
+        double *ta = malloc(sizeof(double) * 2 * TN), *tb = malloc(sizeof(double) * 2 * TN), *ra = malloc(sizeof(double) * 2 * TN), *rb = malloc(sizeof(double) * 2 * TN);
+        for (int k = 0; k < 2 * TN; k++) { ta[k] = 0.25 * k - 3.0; tb[k] = -0.0 * k + 1.0 / (k + 1); }
+        CHECK(rtfhe_twiddles_file_write(path3, TN, ta, tb) == 0);
+        CHECK(rtfhe_twiddles_file_read(path3, TN, ra, rb) == 0 && !memcmp(ta, ra, sizeof(double) * 2 * TN) && !memcmp(tb, rb, sizeof(double) * 2 * TN));
+        CHECK(rtfhe_twiddles_file_read(path3, 2 * TN, ra, rb) != 0);
+        CHECK(rtfhe_twiddles_file_write(path3, 8, ta, tb) != 0 && rtfhe_twiddles_file_read(NULL, TN, ra, rb) != 0);
+        FILE *f = fopen(path3, "r+b"); CHECK(f);
+        fseek(f, 100, SEEK_SET); int c = fgetc(f); fseek(f, 100, SEEK_SET); fputc(c ^ 4, f); fclose(f);
+        CHECK(rtfhe_twiddles_file_read(path3, TN, ra, rb) != 0);
+        f = fopen(path3, "wb"); CHECK(f); fwrite("RTFHETW1", 1, 8, f); fclose(f);
+        CHECK(rtfhe_twiddles_file_read(path3, TN, ra, rb) != 0);
+        free(ta); free(tb); free(ra); free(rb);
+    }
     free(key0); free(key1); free(k0b); free(k1b); free(bk); free(ksk); free(bk2); free(ksk2); free(ct); free(ct2);
     printf("host sanitizer walk ok\n");
     return 0;

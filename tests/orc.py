@@ -101,7 +101,6 @@ def lib():
         "orc_mux": (None, [PP, vp, f64p, u32p, u32p, u32p, u32p, u32p, u32p]),
         "orc_gate_batch_mt": (C.c_double, [PP, C.c_int, C.c_int, f64p, u32p, u32p, u32p, u32p, u32p, C.c_size_t, C.c_int]),
         "orc_gate_batch_mt_numa": (C.c_double, [PP, C.c_int, C.c_int, f64p, u32p, u32p, u32p, C.c_size_t, u32p, C.c_size_t, C.c_int, i32p, i32p, C.c_int]),
-        "orc_stream_read_mt": (C.c_double, [C.c_size_t, C.c_int, C.c_int, i32p]),
         "orc_set_mt_hooks": (None, [vp, vp, vp]),
         "orc_rng_seed": (None, [C.POINTER(Rng), C.c_uint64]),
         "orc_rng_next": (C.c_uint64, [C.POINTER(Rng)]),
@@ -453,12 +452,6 @@ def gate_batch_mt_numa(params, op, bk_f, ksk, in0, in1, count, cpus, node_of, ba
     if secs < 0:
         raise MemoryError("orc_gate_batch_mt_numa: key replica allocation failed")
     return out, secs
-
-
-def stream_read_bandwidth(cpus, bytes_per_thread=256 << 20, passes=3, pin=True):
-    """bytes per second all len(cpus) threads read together from private buffers far larger than their caches"""
-    arr = np.array([c if pin else -1 for c in cpus], np.int32)
-    return lib().orc_stream_read_mt(bytes_per_thread, passes, len(cpus), _p(arr, C.c_int32))
 
 
 _mt_ref = None

@@ -279,3 +279,27 @@ def test_shipped_twiddle_tables_are_the_golden_reference_tables():
     L = R.load()
     assert L.rtfhe_twiddles_load(None, b"/nonexistent", None) == R._ffi.ERR_INVALID
     assert L.rtfhe_twiddles_write(None, b"/nonexistent") == R._ffi.ERR_INVALID
+
+
+def test_twiddle_table_file_roundtrip_and_corruption(tmp_path):
+    """rtfhe_twiddles_file_write / _read (host-only file I/O of the table format): the shipped file reads back as the golden tables, a written
+    file is byte-identical to the shipped one, and a wrong degree, a flipped bit or a truncated file is refused."""
+    import numpy as np
+    import rustfhe_amd as R
+    L = R.load()
+    N = 1024
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fft_N%d.npz" % N))
+    a, b = np.empty(2 * N), np.empty(2 * N)
+    shipped = R.engine.reference_twiddle_file(N)
+    assert L.rtfhe_twiddles_file_read(os.fsencode(shipped), N, a.ctypes.data, b.ctypes.data) == 0
+    assert a.tobytes() == g["ifft_table"].tobytes() and b.tobytes() == g["fft_table"].tobytes()
+    path = str(tmp_path / "tw.bin")
+    assert L.rtfhe_twiddles_file_write(os.fsencode(path), N, a.ctypes.data, b.ctypes.data) == 0
+    assert open(path, "rb").read() == open(shipped, "rb").read()
+    assert L.rtfhe_twiddles_file_read(os.fsencode(path), 2048, np.empty(4096).ctypes.data, np.empty(4096).ctypes.data) == R._ffi.ERR_INVALID
+    raw = bytearray(open(path, "rb").read())
+    raw[1000] ^= 1
+    open(path, "wb").write(bytes(raw))
+    assert L.rtfhe_twiddles_file_read(os.fsencode(path), N, a.ctypes.data, b.ctypes.data) == R._ffi.ERR_INVALID
+    open(path, "wb").write(bytes(raw[:500]))
+    assert L.rtfhe_twiddles_file_read(os.fsencode(path), N, a.ctypes.data, b.ctypes.data) == R._ffi.ERR_INVALID

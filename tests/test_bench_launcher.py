@@ -225,7 +225,7 @@ def test_cpu_baseline_child_measures_tiled_batches_on_pinned_threads(baseline_in
         for run in leg["runs"]:
             assert run["gates_per_thread"] >= 6 and run["gates"] == run["gates_per_thread"] * run["threads_used"] and run["matches_gpu_bit_exact"]
         assert 0 < leg["scaling_efficiency"] <= 1.5
-    assert res["host"]["physical_cores"] >= 1 and res["memory"]["stream_read_GBps"] > 0
+    assert res["host"]["physical_cores"] >= 1
     assert not os.path.exists(child.dir)                        # the scratch directory is gone
 
 
