@@ -507,10 +507,10 @@ int launch_bootstrap_eo11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
 }
 template <int GATES>
 int launch_bootstrap_n2048_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
-    // Measured (profiles/r04/n2048_parity_split_ab.log, same process, identical outputs): where a workgroup holds 1-2 gates (a SIMD then hosts one
-    // wave, or two of one gate with the other SIMDs free) the parity split is 4-5 % faster -- its trades are covered by arithmetic; with 3-4 gates
-    // per workgroup (every SIMD two waves deep, the LDS half full of exchange traffic) the top-bit split is 1-2 % faster.
-    const bool eo = ctx->n2048_kernel < 0 ? GATES <= 2 : ctx->n2048_kernel == 0;
+    // Measured (profiles/r04/n2048_parity_split_ab.log, same process, identical outputs): the parity split is faster at every launch shape --
+    // 4-10 % where a workgroup holds 1-2 gates (its trades are covered by arithmetic), 1.3 % at 4 gates per workgroup once its priority raise
+    // sits inside the wait's assembly statement (no spills), level at 3.  RTFHE_N2048_KERNEL=halves keeps the top-bit split selectable.
+    const bool eo = ctx->n2048_kernel < 0 ? true : ctx->n2048_kernel == 0;
     return eo ? launch_bootstrap_eo11_g<GATES>(ctx, b, s) : launch_bootstrap_halves11_g<GATES>(ctx, b, s);
 }
 

@@ -31,9 +31,9 @@
 #ifndef EO_PRIO_B
 #define EO_PRIO_B 0
 #endif
-// the priority staircase (see EO_PRIO in the kernel): 1 = on (default), 0 = off, 2 = pinned between scheduling barriers (A/B builds)
+// the priority staircase (see EO_STEP in the kernel): -1 = by launch shape (default), 0 = off, 1 = the raise as its own statement, 5 = inside the wait
 #ifndef EO_STAIRS
-#define EO_STAIRS 1
+#define EO_STAIRS -1
 #endif
 
 namespace rtfhe {
@@ -148,19 +148,24 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - H));
     unsigned sync_k = 0;
 #define EO_ARRIVE() pair_arrive(my_flag, ++sync_k)
-    // Priority staircase: both waves run the same code, and of two ready waves a SIMD serves the higher priority (then the older)
-    // almost exclusively -- the leader of a stretch between two trades then idles at the next trade while its partner finishes alone.  Here a
-    // wave's priority falls 3 -> 0 along every stretch (EO_PRIO(k) at fixed code points, back to 3 after every wait): whichever wave is BEHIND is
-    // in an earlier, higher-priority region, so the SIMD favours it until it has caught up.
-    // Measured (profiles/r04/n2048_parity_split_ab.log): 512 gates 11.15 -> 10.65 ms, 1024 gates 16.34 -> 16.18 ms (where the kernel is not the default).
-#if EO_STAIRS == 2      // pinned between scheduling barriers
-#define EO_PRIO(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(k); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif EO_STAIRS == 1
-#define EO_PRIO(k) __builtin_amdgcn_s_setprio(k)
-#else
-#define EO_PRIO(k) do { } while (0)
-#endif
-#define EO_WAIT() do { pair_wait_opaque(partner_flag, sync_k); EO_PRIO(3); } while (0)
+    // Priority staircase: both waves run the same code, and of two ready waves a SIMD serves the higher priority (then the older) almost
+    // exclusively -- the leader of a stretch between two trades then idles at the next trade while its partner finishes alone.  Here a wave's
+    // priority falls 3 -> 0 along every stretch (EO_STEP at fixed code points) and is back at 3 after every wait: whichever wave is BEHIND is in
+    // an earlier, higher-priority region, so the SIMD favours it until it has caught up.
+    // Where the raise sits matters to the COMPILER: every s_setprio is a scheduling boundary.  At 3-4 gates per workgroup (256 registers per
+    // wave) a raise as its own statement behind each of the eight waits costs 15-30 spilled registers, whose reloads queue with the key rows;
+    // inside the wait's own assembly statement (pair_wait_opaque_prio3) it costs none: 16.17 -> 15.49 ms per 1024 gates, and the parity split
+    // then beats the top-bit split (15.69).  At 1-2 gates per workgroup (512 registers, nothing spills) the separate statement measured
+    // faster (10.66 vs 10.89 ms per 512 gates).  EO_STAIRS: -1 = that choice by shape (default), 0 = no staircase, 1 = separate raise,
+    // 5 = fused raise; measured in profiles/r04/n2048_parity_split_ab.log.
+    constexpr int STAIRS = EO_STAIRS < 0 ? (GATES >= 3 ? 5 : 1) : EO_STAIRS;
+    auto eo_prio = [&](auto level) { if constexpr (STAIRS != 0) __builtin_amdgcn_s_setprio(decltype(level)::value); };
+#define EO_STEP(k) eo_prio(std::integral_constant<int, k>{})
+    auto eo_wait = [&]() {
+        if constexpr (STAIRS == 5) pair_wait_opaque_prio3(partner_flag, sync_k);
+        else { pair_wait_opaque(partner_flag, sync_k); EO_STEP(3); }
+    };
+#define EO_WAIT() eo_wait()
 
     const int n = a.n;
     {   // pre-step + mod switch (tfhe.rs:41-71, 97, 107-108) to [0, 2N)
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             int ln = lane0;
             asm volatile("" : "+v"(ln));        // keeps the lane-derived LDS addresses from being hoisted out of the loops and spilled
             EO_STAMP(6);
-            EO_PRIO(2);
+            EO_STEP(2);
             // this lane's 8 complex inputs are points i = 2 (ln + 64 m) + H: coefficients i (real part) and i + 1024 (imaginary part)
             // (rotate: math.rs:85-132; decomposition: math.rs:300-326; twist: spqlios-fft-impl.cpp:496-518)
             cplx tH[R];        // twist factors from global memory: requested before the gather they land under
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
                 for (int m = 0; m < R; m++) {
                     const int c0 = 2 * (ln + 64 * m) + H, c1 = c0 + 1024;
                     const int t0 = e0 + 512 * m, t1 = t0 + 4096;
+                    // (the aligned 8-byte pair + a select instead of the 4-byte read at a stride of two words measured slower: 16.00 vs 15.49 ms)
                     const uint32_t v0 = *reinterpret_cast<const uint32_t*>(pb + (t0 & (4 * N - 4)));
                     const uint32_t v1 = *reinterpret_cast<const uint32_t*>(pb + (t1 & (4 * N - 4)));
                     const uint32_t sg0 = (uint32_t)((int32_t)((uint32_t)t0 << (31 - LOGN - 2)) >> 31);     // all ones iff bit LOGN of (i - r) is set
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
                 }
                 Tw<R - 1> w2;
                 w2.load(tw_p2 + (ln & (G::NLOW - 1)), G::NLOW);
-                EO_PRIO(1);
+                EO_STEP(1);
 #pragma unroll
                 for (int jj = 0; jj < L; jj++) {
                     P12<R, G::LR - 1>::fwd(yr[jj], yi[jj], w2.w);
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             // k_bootstrap_halves): row 0 is written to my buffer, row 1 to the one I read row 0 from, row 2 to the one I read row 1 from.
             Tw<6> w3;
             w3.load(tw_p3, 1);
-            EO_PRIO(0);
+            EO_STEP(0);
             auto pass3 = [&](int jj) { eo_fwd_pass3<R, ODD>(yr[jj], yi[jj], w3.w); };
             pass3(0);
             cross_write(yr[0], yi[0], wbuf, ln); EO_ARRIVE();
@@ -348,10 +354,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             EO_STAMP(4);
             eo_inv_pass3<R, ODD>(re, im, w3.w);
             exchange<10, 3, 2, true>(re, im, wbuf, lane);
-            EO_PRIO(2);
+            EO_STEP(2);
             P12<R, G::LR - 1>::inv(re, im, w2.w);
             exchange<10, 2, 1, true>(re, im, wbuf, lane);
-            EO_PRIO(1);
+            EO_STEP(1);
             P12<R, G::LR - 1>::inv(re, im, w1.w);
             {
                 uint32_t* poly = accbuf + comp * N;

@@ -109,6 +109,24 @@ __device__ __forceinline__ void pair_wait_opaque(unsigned partner_flag_addr, uns
         : "memory", "scc");
 }
 
+// ... and with the wave's priority raised to 3 behind the wait, inside the same statement (a separate s_setprio is one more scheduling boundary
+// for the compiler: in k_bootstrap_eo at 256 registers eight of them per step cost 15 spilled registers)
+__device__ __forceinline__ void pair_wait_opaque_prio3(unsigned partner_flag_addr, unsigned k) {
+    unsigned v, t;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %1, %0\n\t"
+        "s_sub_i32 %1, %1, %3\n\t"
+        "s_cmp_lt_i32 %1, 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_setprio 3"
+        : "=&v"(v), "=&s"(t)
+        : "v"(partner_flag_addr), "s"(k)
+        : "memory", "scc");
+}
+
 template <int R>
 __device__ __forceinline__ void mac_row_first(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
 #pragma unroll

@@ -75,7 +75,8 @@ def test_dp_opcount_formula():
     assert ops["reference"] == 3808 and ops["cvt_trunc"] == 128
     assert ops["total"] == 3808 - 8 * 6 - 16 and ops["add_mul"] == 3680 - 8 * 6 - 16      # unit-twiddle butterflies, first fold row
     assert bench.dp_wave_instr_per_cmux(2048, 3)["transform"] == 800
-    assert bench.dp_wave_instr_per_cmux(2048, 3)["reference"] == 8256 and bench.dp_wave_instr_per_cmux(2048, 3)["total"] == 8256 - 96
+    assert bench.dp_wave_instr_per_cmux(2048, 3)["reference"] == 8256 and bench.dp_wave_instr_per_cmux(2048, 3, "top_bit")["total"] == 8256 - 96
+    assert bench.dp_wave_instr_per_cmux(2048, 3, "parity")["total"] == 8256 - 8 * 18 == bench.dp_wave_instr_per_cmux(2048, 3)["total"]
     assert abs(bench.FP64_VALU_PEAK - 39.3216e12) < 1e6
     assert bench.ALG_BYTES_PER_GATE == 78061008
 
@@ -130,6 +131,7 @@ def test_n2048_parity_split_kernel_executes_the_reference_operation_list(tmp_pat
     ref = bench.dp_wave_instr_per_cmux(2048, 3)["reference"]
     # static = (one polynomial + one component) per parity = half a CMUX step per parity; the even parity saves 18 per transform, 4 transforms in it
     assert f64 == ref // 2 - 4 * 18, (f64, ref)
+    assert 2 * f64 == bench.dp_wave_instr_per_cmux(2048, 3, "parity")["total"]          # the count bench.py prices secondary.config5 with
 
 
 def test_ntt_opcount_formula():
