@@ -35,6 +35,11 @@
 #ifndef EO_STAIRS
 #define EO_STAIRS -1
 #endif
+// the stage across the two waves: 1 = each wave finishes BOTH outputs of the butterflies of half of the indices k (it sends 4 of its 8 values per
+// lane and receives 4), 0 = each wave finishes one output of every butterfly (sends 8, receives 8: the first form of this kernel, A/B builds)
+#ifndef EO_HALF_TRADE
+#define EO_HALF_TRADE 1
+#endif
 
 namespace rtfhe {
 
@@ -64,18 +69,25 @@ struct EoLds {
 struct EoArgs {
     BootstrapArgs b;       // b.tw / b.bk unused
     const cplx* etw;       // [EoTw::TOTAL]
-    const cplx* ebk;       // [n][2l rows][2 comp][2 parity][8][64]
+    const cplx* ebk;       // [n][2l rows][2 comp][2 waves][8][64]: k_bk_to_eo
 };
 
-// key spectra: device layout of k_bootstrap<11> ([n][row][comp][16][64]: lane v, register m <-> point (v << 4) | m) -> even / odd layout
-// (lane v, register m of parity H <-> point 2 (8 v + m) + H = (v << 4) | (2 m + H))
+// key spectra: device layout of k_bootstrap<11> ([n][row][comp][16][64]: lane v, register q <-> point (v << 4) | q) -> the layout the waves of
+// k_bootstrap_eo hold their spectra in after the stage across them.  A parity's sub-network leaves lane v, register m with its output k = 8 v + m;
+// the stage across the waves makes points 2k (sum) and 2k + 1 (difference).  Wave H finishes both for m = 4 H + j, j < 4: register j holds point
+// 2k = (v << 4) | (8 H + 2 j), register 4 + j point 2k + 1.  (EO_HALF_TRADE=0: wave H holds point 2k + H of every k: register m <-> q = 2 m + H.)
 __global__ __launch_bounds__(256) void k_bk_to_eo(const cplx* __restrict__ src, cplx* __restrict__ dst, size_t polys) {
     const size_t total = polys * 1024;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t g = idx >> 10;
-        const int k = (int)(idx & 1023);                 // destination: (H, m, lane)
+        const int k = (int)(idx & 1023);                 // destination: (H, register, lane)
         const int H = k >> 9, m = (k >> 6) & 7, lane = k & 63;
-        dst[idx] = src[g * 1024 + (size_t)(2 * m + H) * 64 + lane];
+#if EO_HALF_TRADE
+        const int q = 8 * H + 2 * (m & 3) + (m >> 2);
+#else
+        const int q = 2 * m + H;
+#endif
+        dst[idx] = src[g * 1024 + (size_t)q * 64 + lane];
     }
 }
 
@@ -217,9 +229,49 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
 #define EO_STAMP(k) do { } while (0)
 #endif
 
+#if EO_HALF_TRADE
+    // The size-2 stage across the waves, forward (the LAST stage: sub-network outputs out_E[k], out_O[k] -> points 2k = out_E + out_O, 2k + 1 =
+    // out_E + (-out_O)).  A lane holds k = 8 v + m, m < 8, of its parity.  The even wave finishes both points for m < 4, the odd wave for m >= 4:
+    // each sends the four values the other needs and receives four -- half the LDS traffic of "every wave finishes its parity of every k", the
+    // same sums.  Afterwards register j < 4 holds point 2k, register 4 + j point 2k + 1, k = 8 v + 4 H + j (the key's layout: k_bk_to_eo).
+    auto cross_write = [&](auto odd, const double (&re)[R], const double (&im)[R], double* wb, int ln) {
+        constexpr int SEND = decltype(odd)::value ? 0 : R / 2;
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) { lds_st(&wb[ln + 64 * j], re[SEND + j]); lds_st(&wb[G::XSLOTS + ln + 64 * j], im[SEND + j]); }
+    };
+    auto cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) {
+            const double pr = lds_ld(&rb[ln + 64 * j]), pi = lds_ld(&rb[G::XSLOTS + ln + 64 * j]);
+            if constexpr (!decltype(odd)::value) {      // mine = out_E, partner's = out_O
+                const double ar = re[j], ai = im[j];
+                re[j] = ar + pr; im[j] = ai + pi; re[R / 2 + j] = ar + (-pr); im[R / 2 + j] = ai + (-pi);
+            } else {                                    // partner's = out_E, mine = out_O
+                const double br = re[R / 2 + j], bi = im[R / 2 + j];
+                re[j] = pr + br; im[j] = pi + bi; re[R / 2 + j] = pr + (-br); im[R / 2 + j] = pi + (-bi);
+            }
+        }
+    };
+    // ... inverse (the FIRST stage: points 2k, 2k + 1 -> in_E[k] = sum, in_O[k] = difference): both inputs of a butterfly are in one lane (registers
+    // j, 4 + j); the even wave keeps the sums, the odd wave the differences, and the four they do not keep go to the partner.
+    auto inv_cross_write = [&](auto odd, double (&re)[R], double (&im)[R], double* wb, int ln) {
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) {
+            const double ar = re[j], br = re[R / 2 + j], ai = im[j], bi = im[R / 2 + j];
+            const double sr = ar + br, si = ai + bi, dr = ar + (-br), di = ai + (-bi);
+            if constexpr (!decltype(odd)::value) { re[j] = sr; im[j] = si; lds_st(&wb[ln + 64 * j], dr); lds_st(&wb[G::XSLOTS + ln + 64 * j], di); }
+            else { re[R / 2 + j] = dr; im[R / 2 + j] = di; lds_st(&wb[ln + 64 * j], sr); lds_st(&wb[G::XSLOTS + ln + 64 * j], si); }
+        }
+    };
+    auto inv_cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
+        constexpr int RECV = decltype(odd)::value ? 0 : R / 2;      // even: the odd wave's sums for m >= 4; odd: the even wave's differences for m < 4
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) { re[RECV + j] = lds_ld(&rb[ln + 64 * j]); im[RECV + j] = lds_ld(&rb[G::XSLOTS + ln + 64 * j]); }
+    };
+#else
     // one row's cross-wave size-2 stage after the trade: mine / partner's are out_H[k], point 2k = out_0 + out_1, point 2k+1 = out_0 + (-out_1)
-    auto cross_read = [&](bool odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
-        if (!odd) {
+    auto cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
+        if constexpr (!decltype(odd)::value) {
 #pragma unroll
             for (int m = 0; m < R; m++) { re[m] = re[m] + lds_ld(&rb[ln + 64 * m]); im[m] = im[m] + lds_ld(&rb[G::XSLOTS + ln + 64 * m]); }
         } else {
@@ -227,10 +279,13 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             for (int m = 0; m < R; m++) { re[m] = lds_ld(&rb[ln + 64 * m]) + (-re[m]); im[m] = lds_ld(&rb[G::XSLOTS + ln + 64 * m]) + (-im[m]); }
         }
     };
-    auto cross_write = [&](const double (&re)[R], const double (&im)[R], double* wb, int ln) {
+    auto cross_write = [&](auto, const double (&re)[R], const double (&im)[R], double* wb, int ln) {
 #pragma unroll
         for (int m = 0; m < R; m++) { lds_st(&wb[ln + 64 * m], re[m]); lds_st(&wb[G::XSLOTS + ln + 64 * m], im[m]); }
     };
+    auto inv_cross_write = [&](auto odd, double (&re)[R], double (&im)[R], double* wb, int ln) { cross_write(odd, re, im, wb, ln); };
+    auto inv_cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) { cross_read(odd, re, im, rb, ln); };
+#endif
 
     // The whole step loop exists twice, once per parity, chosen ONCE (the waves of a workgroup meet at no barrier inside it): with the parity a
     // compile-time constant each copy is straight-line code.  A wave-uniform branch on H around the few places that differ (the size-4 half
@@ -312,13 +367,13 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             EO_STEP(0);
             auto pass3 = [&](int jj) { eo_fwd_pass3<R, ODD>(yr[jj], yi[jj], w3.w); };
             pass3(0);
-            cross_write(yr[0], yi[0], wbuf, ln); EO_ARRIVE();
+            cross_write(parity, yr[0], yi[0], wbuf, ln); EO_ARRIVE();
             pass3(1);
-            EO_WAIT(); cross_read(ODD, yr[0], yi[0], rbuf, ln);
-            cross_write(yr[1], yi[1], rbuf, ln); EO_ARRIVE();
+            EO_WAIT(); cross_read(parity, yr[0], yi[0], rbuf, ln);
+            cross_write(parity, yr[1], yi[1], rbuf, ln); EO_ARRIVE();
             pass3(2);
-            EO_WAIT(); cross_read(ODD, yr[1], yi[1], wbuf, ln);
-            cross_write(yr[2], yi[2], wbuf, ln); EO_ARRIVE();
+            EO_WAIT(); cross_read(parity, yr[1], yi[1], wbuf, ln);
+            cross_write(parity, yr[2], yi[2], wbuf, ln); EO_ARRIVE();
             fetch(bB, i, rc0 + 1);                      // (row 0, c1): requested once pass 3's twiddles are dead (both buffers live through pass 3 spill)
             EO_STAMP(2);
             // hadamard + fold-add (spqlios.rs:204-222, trgsw.rs:290-299): this wave's parity of the points; each accumulator folds the
@@ -327,7 +382,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             mac_row<R>(s1re, s1im, bB, yr[0], yi[0]); fetch(bB, i, rc0 + 3);           // (row 1, c1)
             mac_row<R>(s0re, s0im, bA, yr[1], yi[1]); fetch(bA, i, rc0 + 4);           // (row 2, c0)
             mac_row<R>(s1re, s1im, bB, yr[1], yi[1]); fetch(bB, i, rc0 + 5);           // (row 2, c1)
-            EO_WAIT(); cross_read(ODD, yr[2], yi[2], rbuf, ln);
+            EO_WAIT(); cross_read(parity, yr[2], yi[2], rbuf, ln);
             { double* t = wbuf; wbuf = rbuf; rbuf = t; }        // three trades: I now own the buffer I read last
             mac_row<R>(s0re, s0im, bA, yr[2], yi[2]);
             mac_row<R>(s1re, s1im, bB, yr[2], yi[2]);
@@ -342,14 +397,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             for (int m = 0; m < R; m++) { re[m] = comp ? s1re[m] : s0re[m]; im[m] = comp ? s1im[m] : s0im[m]; }
             int lane = lane0;
             asm volatile("" : "+v"(lane));
-            cross_write(re, im, wbuf, lane); EO_ARRIVE();
+            inv_cross_write(parity, re, im, wbuf, lane); EO_ARRIVE();
             Tw<6> w3; Tw<R - 1> w2, w1; Tw<R> wt;
             w1.load(gip10 + lane, 64);                  // global memory: requested first, used last
 #pragma unroll
             for (int m = 0; m < R; m++) wt.w[m] = guntw0[m * 64 + lane];
             w3.load(twi_p3, 1);
             w2.load(twi_p2 + (lane & (G::NLOW - 1)), G::NLOW);
-            EO_WAIT(); cross_read(ODD, re, im, rbuf, lane);
+            EO_WAIT(); inv_cross_read(parity, re, im, rbuf, lane);
             { double* t = wbuf; wbuf = rbuf; rbuf = t; }
             EO_STAMP(4);
             eo_inv_pass3<R, ODD>(re, im, w3.w);
