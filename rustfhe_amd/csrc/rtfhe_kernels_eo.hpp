@@ -40,6 +40,17 @@
 #ifndef EO_HALF_TRADE
 #define EO_HALF_TRADE 1
 #endif
+// the inverse transforms of the two components: 1 = a loop, 2 = two copies of the code, 0 = by launch shape (default; see COMP_COPIES in the kernel)
+#ifndef EO_COMP_COPIES
+#define EO_COMP_COPIES 0
+#endif
+// (The accumulator as two parity planes per polynomial in LDS -- coefficient c at word 1024 (c & 1) + (c >> 1), so that a wave's gather and update touch
+// consecutive words instead of every second one -- removes the gather's 2-way bank conflicts (0.33 G conflict cycles per 1024-gate launch) and
+// measured +-0 to +1.4 %: 15.27 -> 15.34 ms per 1024 gates, 13.20 -> 13.39 per 768; the compiler's address arithmetic for it is two integer
+// instructions per coefficient longer.  profiles/r04/n2048_accumulator_planes_ab.log.  Not kept.)
+// (With half-width trades a buffer holds two of them.  Rows 0 and 1 of a polynomial in ONE trade -- 6 arrive / wait pairs per step instead of 8 --
+// measured +-0: 14.85 -> 14.81 ms per 1024 gates, 13.02 -> 13.17 per 768, profiles/r04/n2048_merged_trades_ab.log; the two components' sums before
+// the inverse in one trade as well made the register allocator spill 340 registers at 3-4 gates per workgroup.  Not kept.)
 
 namespace rtfhe {
 
@@ -255,13 +266,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     // ... inverse (the FIRST stage: points 2k, 2k + 1 -> in_E[k] = sum, in_O[k] = difference): both inputs of a butterfly are in one lane (registers
     // j, 4 + j); the even wave keeps the sums, the odd wave the differences, and the four they do not keep go to the partner.
     auto inv_cross_write = [&](auto odd, double (&re)[R], double (&im)[R], double* wb, int ln) {
+        constexpr int SEND = decltype(odd)::value ? 0 : R / 2;      // sums stay in registers j, differences in 4 + j; the partner's overwrite what was sent
 #pragma unroll
         for (int j = 0; j < R / 2; j++) {
             const double ar = re[j], br = re[R / 2 + j], ai = im[j], bi = im[R / 2 + j];
-            const double sr = ar + br, si = ai + bi, dr = ar + (-br), di = ai + (-bi);
-            if constexpr (!decltype(odd)::value) { re[j] = sr; im[j] = si; lds_st(&wb[ln + 64 * j], dr); lds_st(&wb[G::XSLOTS + ln + 64 * j], di); }
-            else { re[R / 2 + j] = dr; im[R / 2 + j] = di; lds_st(&wb[ln + 64 * j], sr); lds_st(&wb[G::XSLOTS + ln + 64 * j], si); }
+            re[j] = ar + br; im[j] = ai + bi; re[R / 2 + j] = ar + (-br); im[R / 2 + j] = ai + (-bi);
         }
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) { lds_st(&wb[ln + 64 * j], re[SEND + j]); lds_st(&wb[G::XSLOTS + ln + 64 * j], im[SEND + j]); }
     };
     auto inv_cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
         constexpr int RECV = decltype(odd)::value ? 0 : R / 2;      // even: the odd wave's sums for m >= 4; odd: the even wave's differences for m < 4
@@ -390,8 +402,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
         }
 
         // inverse: the size-2 stage across the waves comes FIRST (decimation in time), then this parity's sub-network, untwist, truncate, += acc
-#pragma unroll 1
+        // At 1-3 gates per workgroup the two components are two copies of the code (no selects of the 32 accumulator registers: 0.5-1.1 % faster,
+        // profiles/r04/n2048_unrolled_components_ab.log); at 4 the copy measured +-0 and the loop keeps 11 KiB of instruction cache free.
+        constexpr int COMP_COPIES = EO_COMP_COPIES ? EO_COMP_COPIES : (GATES <= 3 ? 2 : 1);
+#pragma unroll COMP_COPIES
         for (int comp = 0; comp < 2; comp++) {
+            if (COMP_COPIES == 2) __builtin_amdgcn_sched_barrier(0);      // the copies one after the other, not interleaved
             double re[R], im[R];
 #pragma unroll
             for (int m = 0; m < R; m++) { re[m] = comp ? s1re[m] : s0re[m]; im[m] = comp ? s1im[m] : s0im[m]; }
