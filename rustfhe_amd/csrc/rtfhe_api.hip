@@ -201,6 +201,38 @@ struct HostTw {
         return t;
     }
 
+    // tables of the parity sub-networks of the latency kernel (N = 1024; layout: Q4Tw, rtfhe_sub256.hpp): wave H owns the points i = 2 j + H of a
+    // 512-point transform and runs its twiddled stages on the 256-point sub-sequence j; the twiddle of pair (i, i + halfnn) is entry
+    // i mod halfnn = 2 (j mod halfnn / 2) + H of the reference's stage table
+    std::vector<cplx> q4_table() const {
+        std::vector<cplx> t(Q4Tw::TOTAL, make_double2(0.0, 0.0));
+        const double fold = 2.0 / (double)N;      // the inverse's input scaling (fft_processor_spqlios.cpp:158), exact, folded into the untwist
+        for (int dir = 0; dir < 2; dir++)
+            for (int H = 0; H < 2; H++) {
+                cplx* d = t.data() + Q4Tw::off(dir, H);
+                const double* sc = dir ? inv_c.data() : fwd_c.data();
+                const double* ss = dir ? inv_s.data() : fwd_s.data();
+                auto off = [&](int halfnn) { return dir ? inv_off(halfnn) : fwd_off(halfnn); };
+                auto entry = [&](int halfnn, int k) { return make_double2(sc[off(halfnn) + k], ss[off(halfnn) + k]); };
+                for (int m = 0; m < 4; m++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int i = 2 * (lane + 64 * m) + H;
+                        d[Q4Tw::TW + m * 64 + lane] = dir ? make_double2(untw_c[i] * fold, untw_s[i] * fold) : make_double2(twist_c[i], twist_s[i]);
+                    }
+                for (int mb = 1; mb >= 0; mb--) {
+                    const int h = 1 << mb;
+                    for (int q = 0; q < h; q++) {
+                        const int e = 4 - 2 * h + q;
+                        for (int lane = 0; lane < 64; lane++) d[Q4Tw::P1 + e * 64 + lane] = entry(128 * h, 2 * (lane + 64 * q) + H);     // pass 1: j-halfnn 64 h
+                        for (int r = 0; r < 16; r++) d[Q4Tw::P2 + e * 16 + r] = entry(32 * h, 2 * ((q << 4) | r) + H);                  // pass 2: j-halfnn 16 h
+                        for (int c = 0; c < 4; c++) d[Q4Tw::P3 + e * 4 + c] = entry(8 * h, 2 * ((q << 2) | c) + H);                     // pass 3: j-halfnn 4 h
+                    }
+                }
+                for (int q = 0; q < 2; q++) d[Q4Tw::P4 + q] = entry(4, 2 * q + H);                                                      // pass 4: i-halfnn 4
+            }
+        return t;
+    }
+
     // device table: per direction [twist R*64][pass1 (R-1)*64][pass2 (R-1)*NLOW][pass3 NLOW-4]
     template <int LOGN>
     std::vector<cplx> device_table() const {
@@ -873,6 +905,10 @@ int upload_twiddles(rtfhe_ctx* ctx) {
         return fail(ctx, RTFHE_ERR_INVALID, "twiddle table: the first entry of the halfnn = 4 and 8 stages must be exactly (1, 0) in both directions "
                                             "(cos 0, sin 0: true of every table the reference builds)");
     std::vector<cplx> t = ctx->logn == 10 ? ctx->tw.device_table<10>() : ctx->tw.device_table<11>();
+    if (ctx->logn == 10) {      // the latency kernel's parity tables ride behind the table every kernel stages into LDS (k_bootstrap_wg reads them from there)
+        const std::vector<cplx> q = ctx->tw.q4_table();
+        t.insert(t.end(), q.begin(), q.end());
+    }
     if (!ctx->d_tw) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_tw, t.size() * sizeof(cplx)));
     HIPCHECK(ctx, hipMemcpy(ctx->d_tw, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice));
     if (ctx->logn == 11) {

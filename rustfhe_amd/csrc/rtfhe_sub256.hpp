@@ -1,0 +1,136 @@
+// rtfhe_sub256.hpp -- one PARITY of the 512-point transform (N = 1024) on one wave: 4 points per lane.
+//
+// The latency kernel (rtfhe_kernels_wg.hpp) has eight waves for one gate and, per CMUX step, phases in which only some of them have a
+// whole transform to run.  A transform splits over two waves the way k_bootstrap_eo splits the 1024-point one (rtfhe_kernels_eo.hpp):
+// wave H owns the points of parity H, i = 2 j + H.  Every radix-2 stage pairs i with i + halfnn, of the same parity for halfnn >= 2, so
+// the twist, the seven twiddled stages halfnn = 256 .. 4 and this parity's half of the size-4 stage (spqlios-fft-impl.cpp:526-603 forward,
+// :289-363 inverse) stay inside the wave, as a 256-point network in j; the twiddle of pair (i, i + halfnn) is entry i mod halfnn =
+// 2 (j mod halfnn / 2) + H of the reference's stage table.  Only the untwiddled size-2 stage (x0 + x1, x0 + (-x1); :606-634 / :248-269)
+// pairs the parities: the caller does it where both values already meet (the spectrum buffer in LDS).
+//
+// Four points per lane = two stages per in-register pass = four passes and three wave-private exchanges:
+//   layout L1: lane t, register m <-> j = t + 64 m                                      (m = bits 7..6)   stages j-halfnn 128, 64
+//   layout L2: lane (a, r),  m   <-> j = (a << 6) | (m << 4) | r,  a = lane >> 4, r = lane & 15  (bits 5..4)          32, 16
+//   layout L3: lane (b, c),  m   <-> j = (b << 4) | (m << 2) | c,  b = lane >> 2, c = lane & 3   (bits 3..2)           8,  4
+//   layout L4: lane v,       m   <-> j = (v << 2) | m                                    (bits 1..0)   j-halfnn 2 and the size-4 half
+// Same butterflies (fwd_stage_tw / inv_stage_tw), same operands, same order per point as the one-wave transform: bit-identical.
+#pragma once
+
+#include "rtfhe_device.hpp"
+
+namespace rtfhe {
+
+// tables, cplx units: [direction 0 = forward, 1 = inverse][parity][ONE]
+struct Q4Tw {
+    static constexpr int TW = 0;                 // [4][64]  forward: twist of point i = 2 (lane + 64 m) + H; inverse: untwist times 2/N
+    static constexpr int P1 = TW + 4 * 64;       // [3][64]  entries of Tw<3>: e = 0, 1: i-halfnn 256, q = e; e = 2: i-halfnn 128
+    static constexpr int P2 = P1 + 3 * 64;       // [3][16]  i-halfnn 64 (q = 0, 1), 32; by r = lane & 15
+    static constexpr int P3 = P2 + 3 * 16;       // [3][4]   i-halfnn 16 (q = 0, 1), 8;  by c = lane & 3
+    static constexpr int P4 = P3 + 3 * 4;        // [2]      i-halfnn 4, q = 0, 1 (wave-uniform)
+    static constexpr int ONE = 512;
+    static constexpr int TOTAL = 4 * ONE;
+    __host__ __device__ static constexpr int off(int dir, int H) { return (dir * 2 + H) * ONE; }
+};
+
+// the twiddles one wave uses for one direction and parity: 15 complex values, loaded once and kept in registers over the whole blind rotation
+struct Q4Regs {
+    cplx wt[4], w1[3], w2[3], w3[3], w4[2];
+    __device__ __forceinline__ void load(const cplx* __restrict__ t, int lane) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) wt[m] = t[Q4Tw::TW + m * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            w1[e] = t[Q4Tw::P1 + e * 64 + lane];
+            w2[e] = t[Q4Tw::P2 + e * 16 + (lane & 15)];
+            w3[e] = t[Q4Tw::P3 + e * 4 + (lane & 3)];
+        }
+        w4[0] = t[Q4Tw::P4]; w4[1] = t[Q4Tw::P4 + 1];
+    }
+};
+
+struct Q4 {
+    static constexpr int R = 4;
+    static constexpr int XS = 320;               // doubles per plane of an exchange buffer (the largest padded slot is 318)
+    // Slot of register m in the buffer of the exchange between layouts X and X + 1: base(lane) + stride * m, with the pads
+    //   L1 <-> L2: slot(j) = j + 16 (j >> 6)     L2 <-> L3: j + 4 (j >> 4)     L3 <-> L4: j + (j >> 2)
+    // chosen so that the 32 lanes of a half-wave hit 32 different 8-byte bank pairs on the write AND on the read side.
+    template <int X, int LAYOUT>
+    __device__ __forceinline__ static int base(int lane) {
+        if constexpr (X == 1) return LAYOUT == 1 ? lane : 80 * (lane >> 4) + (lane & 15);
+        else if constexpr (X == 2) return LAYOUT == 2 ? 80 * (lane >> 4) + (lane & 15) : 20 * (lane >> 2) + (lane & 3);
+        else return LAYOUT == 3 ? 20 * (lane >> 2) + (lane & 3) : 5 * lane;
+    }
+    template <int X, int LAYOUT>
+    __host__ __device__ static constexpr int stride() {
+        return X == 1 ? (LAYOUT == 1 ? 80 : 16) : X == 2 ? (LAYOUT == 2 ? 20 : 4) : (LAYOUT == 3 ? 5 : 1);
+    }
+    template <int FROM, int TO>
+    __device__ __forceinline__ static void exchange(double (&re)[R], double (&im)[R], double* __restrict__ xre, double* __restrict__ xim, int lane) {
+        constexpr int X = FROM < TO ? FROM : TO;
+        static_assert(FROM + TO == 2 * X + 1, "neighbouring layouts");
+        const int bw = base<X, FROM>(lane), br = base<X, TO>(lane);
+        constexpr int sw = stride<X, FROM>(), sr = stride<X, TO>();
+#pragma unroll
+        for (int m = 0; m < R; m++) lds_st(&xre[bw + sw * m], re[m]);
+#pragma unroll
+        for (int m = 0; m < R; m++) lds_st(&xim[bw + sw * m], im[m]);
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) {        // the next pass's first stage pairs m with m + 2
+            re[m] = lds_ld(&xre[br + sr * m]); re[m + 2] = lds_ld(&xre[br + sr * (m + 2)]);
+            im[m] = lds_ld(&xim[br + sr * m]); im[m + 2] = lds_ld(&xim[br + sr * (m + 2)]);
+        }
+        wave_lds_sync();
+    }
+};
+
+// Forward: in = this parity's points in layout L1 (digits, not yet twisted); out = the sub-network's outputs out_H[j] in layout L4,
+// i.e. what the size-2 stage across the parities still has to combine (spectrum point 2 j = out_0[j] + out_1[j], 2 j + 1 = out_0[j] + (-out_1[j])).
+struct Q4NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <bool ODD, bool TRIV, typename HOOK = Q4NoHook>
+__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const Q4Regs& w, double* __restrict__ xre, double* __restrict__ xim, int lane,
+                                               HOOK after_exchange = HOOK()) {
+    twist_mul<4>(re, im, w.wt);
+    P12<4, 1>::fwd(re, im, w.w1);
+    Q4::exchange<1, 2>(re, im, xre, xim, lane);
+    after_exchange(1);
+    P12<4, 1>::fwd(re, im, w.w2);
+    Q4::exchange<2, 3>(re, im, xre, xim, lane);
+    after_exchange(2);
+    P12<4, 1>::fwd(re, im, w.w3);
+    Q4::exchange<3, 4>(re, im, xre, xim, lane);
+    after_exchange(3);
+    fwd_stage_tw<4, 1, TRIV && !ODD>(re, im, w.w4);       // i-halfnn 4; entry 0 of parity 0 is the reference's (1, 0): see fwd_stage_tw
+    // this parity's half of the size-4 stage (spqlios-fft-impl.cpp:581-602): even points x0, x2 -> x0 + x2, x0 + (-x2); odd points x1, x3 ->
+    // x1 + x3, i (x1 - x3) = ((-j1) + j3, r1 + (-r3))
+#pragma unroll
+    for (int m = 0; m < 4; m += 2) {
+        const double ra = re[m], rb = re[m + 1], ja = im[m], jb = im[m + 1];
+        if (!ODD) { re[m] = ra + rb; re[m + 1] = ra + (-rb); im[m] = ja + jb; im[m + 1] = ja + (-jb); }
+        else      { re[m] = ra + rb; re[m + 1] = (-ja) + jb; im[m] = ja + jb; im[m + 1] = ra + (-rb); }
+    }
+}
+
+// Inverse: in = in_H[j] in layout L4 (the size-2 stage across the parities already applied: in_0[j] = s[2j] + s[2j + 1], in_1[j] = s[2j] + (-s[2j + 1]));
+// out = this parity's coefficients, untwisted (the 2/N of fft_processor_spqlios.cpp:158 is in the table), layout L1.
+template <bool ODD, bool TRIV>
+__device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4], const Q4Regs& w, double* __restrict__ xre, double* __restrict__ xim, int lane) {
+    // this parity's half of the size-4 stage (:289-310): even x0, x2 -> x0 + x2, x0 + (-x2); odd x1, x3 -> x1 - i x3 = (r1 + j3, j1 + (-r3)),
+    // x1 + i x3 = (r1 + (-j3), j1 + r3)
+#pragma unroll
+    for (int m = 0; m < 4; m += 2) {
+        const double ra = re[m], rb = re[m + 1], ja = im[m], jb = im[m + 1];
+        if (!ODD) { re[m] = ra + rb; re[m + 1] = ra + (-rb); im[m] = ja + jb; im[m + 1] = ja + (-jb); }
+        else      { re[m] = ra + jb; re[m + 1] = ra + (-jb); im[m] = ja + (-rb); im[m + 1] = ja + rb; }
+    }
+    inv_stage_tw<4, 1, false, TRIV && !ODD>(re, im, w.w4);
+    Q4::exchange<4, 3>(re, im, xre, xim, lane);
+    P12<4, 1>::inv(re, im, w.w3);
+    Q4::exchange<3, 2>(re, im, xre, xim, lane);
+    P12<4, 1>::inv(re, im, w.w2);
+    Q4::exchange<2, 1>(re, im, xre, xim, lane);
+    P12<4, 1>::inv(re, im, w.w1);
+    twist_mul<4>(re, im, w.wt);
+}
+
+}  // namespace rtfhe

@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import rustfhe_amd.build as b
-b.LIB = os.path.join(ROOT, "scripts", "ubench", "librtfhe_stamps.so")
+b.LIB = os.environ.get("RTFHE_STAMPS_LIB_PATH") or os.path.join(ROOT, "scripts", "ubench", "librtfhe_stamps.so")
 b.build = lambda *a, **k: b.LIB
 import rustfhe_amd as R
 P = R.Params()
