@@ -46,8 +46,12 @@ struct Q4Regs {
         }
         w4[0] = t[Q4Tw::P4]; w4[1] = t[Q4Tw::P4 + 1];
     }
+    __device__ __forceinline__ void get_wt(cplx (&o)[4]) const { for (int m = 0; m < 4; m++) o[m] = wt[m]; }
+    __device__ __forceinline__ void get_w1(cplx (&o)[3]) const { for (int e = 0; e < 3; e++) o[e] = w1[e]; }
+    __device__ __forceinline__ void get_w2(cplx (&o)[3]) const { for (int e = 0; e < 3; e++) o[e] = w2[e]; }
+    __device__ __forceinline__ void get_w3(cplx (&o)[3]) const { for (int e = 0; e < 3; e++) o[e] = w3[e]; }
+    __device__ __forceinline__ void get_w4(cplx (&o)[2]) const { o[0] = w4[0]; o[1] = w4[1]; }
 };
-
 struct Q4 {
     static constexpr int R = 4;
     static constexpr int XS = 320;               // doubles per plane of an exchange buffer (the largest padded slot is 318)
@@ -87,20 +91,25 @@ struct Q4 {
 // Forward: in = this parity's points in layout L1 (digits, not yet twisted); out = the sub-network's outputs out_H[j] in layout L4,
 // i.e. what the size-2 stage across the parities still has to combine (spectrum point 2 j = out_0[j] + out_1[j], 2 j + 1 = out_0[j] + (-out_1[j])).
 struct Q4NoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <bool ODD, bool TRIV, typename HOOK = Q4NoHook>
-__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const Q4Regs& w, double* __restrict__ xre, double* __restrict__ xim, int lane,
+template <bool ODD, bool TRIV, typename W, typename HOOK = Q4NoHook>
+__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const W& w, double* __restrict__ xre, double* __restrict__ xim, int lane,
                                                HOOK after_exchange = HOOK()) {
-    twist_mul<4>(re, im, w.wt);
-    P12<4, 1>::fwd(re, im, w.w1);
+    cplx wt[4], w1[3], w2[3], w3[3], w4[2];
+    w.get_wt(wt); w.get_w1(w1);
+    twist_mul<4>(re, im, wt);
+    P12<4, 1>::fwd(re, im, w1);
+    w.get_w2(w2);
     Q4::exchange<1, 2>(re, im, xre, xim, lane);
     after_exchange(1);
-    P12<4, 1>::fwd(re, im, w.w2);
+    P12<4, 1>::fwd(re, im, w2);
+    w.get_w3(w3);
     Q4::exchange<2, 3>(re, im, xre, xim, lane);
     after_exchange(2);
-    P12<4, 1>::fwd(re, im, w.w3);
+    P12<4, 1>::fwd(re, im, w3);
+    w.get_w4(w4);
     Q4::exchange<3, 4>(re, im, xre, xim, lane);
     after_exchange(3);
-    fwd_stage_tw<4, 1, TRIV && !ODD>(re, im, w.w4);       // i-halfnn 4; entry 0 of parity 0 is the reference's (1, 0): see fwd_stage_tw
+    fwd_stage_tw<4, 1, TRIV && !ODD>(re, im, w4);       // i-halfnn 4; entry 0 of parity 0 is the reference's (1, 0): see fwd_stage_tw
     // this parity's half of the size-4 stage (spqlios-fft-impl.cpp:581-602): even points x0, x2 -> x0 + x2, x0 + (-x2); odd points x1, x3 ->
     // x1 + x3, i (x1 - x3) = ((-j1) + j3, r1 + (-r3))
 #pragma unroll
@@ -113,8 +122,10 @@ __device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4],
 
 // Inverse: in = in_H[j] in layout L4 (the size-2 stage across the parities already applied: in_0[j] = s[2j] + s[2j + 1], in_1[j] = s[2j] + (-s[2j + 1]));
 // out = this parity's coefficients, untwisted (the 2/N of fft_processor_spqlios.cpp:158 is in the table), layout L1.
-template <bool ODD, bool TRIV>
-__device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4], const Q4Regs& w, double* __restrict__ xre, double* __restrict__ xim, int lane) {
+template <bool ODD, bool TRIV, typename W>
+__device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4], const W& w, double* __restrict__ xre, double* __restrict__ xim, int lane) {
+    cplx wt[4], w1[3], w2[3], w3[3], w4[2];
+    w.get_w4(w4); w.get_w3(w3);
     // this parity's half of the size-4 stage (:289-310): even x0, x2 -> x0 + x2, x0 + (-x2); odd x1, x3 -> x1 - i x3 = (r1 + j3, j1 + (-r3)),
     // x1 + i x3 = (r1 + (-j3), j1 + r3)
 #pragma unroll
@@ -123,14 +134,16 @@ __device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4],
         if (!ODD) { re[m] = ra + rb; re[m + 1] = ra + (-rb); im[m] = ja + jb; im[m + 1] = ja + (-jb); }
         else      { re[m] = ra + jb; re[m + 1] = ra + (-jb); im[m] = ja + (-rb); im[m + 1] = ja + rb; }
     }
-    inv_stage_tw<4, 1, false, TRIV && !ODD>(re, im, w.w4);
+    inv_stage_tw<4, 1, false, TRIV && !ODD>(re, im, w4);
     Q4::exchange<4, 3>(re, im, xre, xim, lane);
-    P12<4, 1>::inv(re, im, w.w3);
+    P12<4, 1>::inv(re, im, w3);
+    w.get_w2(w2);
     Q4::exchange<3, 2>(re, im, xre, xim, lane);
-    P12<4, 1>::inv(re, im, w.w2);
+    P12<4, 1>::inv(re, im, w2);
+    w.get_w1(w1); w.get_wt(wt);
     Q4::exchange<2, 1>(re, im, xre, xim, lane);
-    P12<4, 1>::inv(re, im, w.w1);
-    twist_mul<4>(re, im, w.wt);
+    P12<4, 1>::inv(re, im, w1);
+    twist_mul<4>(re, im, wt);
 }
 
 }  // namespace rtfhe
