@@ -5,16 +5,23 @@
 // and single hom_nand() calls are small; here the 8 waves of a 512-thread workgroup share one gate:
 //
 //   per CMUX step (same arithmetic, same operation order as the reference -- see cmux_step for citations):
-//     F  waves 0..2l-1 : wave j gathers/decomposes digit polynomial j and runs its forward transform, spectrum -> LDS;
-//                        the transforms of the last two rows are cut at their first exchange and finished by waves 2l, 2l+1
-//                        on the two SIMDs that host only one F-wave (release/acquire flag in LDS, no barrier)
+//     F  waves 0..2l-3 : wave j gathers/decomposes digit polynomial j and runs its forward transform, spectrum -> LDS;
+//        waves 2l-2..2l+1: the last two rows, each on TWO waves split by the parity of the point index (rtfhe_sub256.hpp): a wave gathers its
+//                        parity's 256 points and runs their sub-network (4 points per lane); the size-2 stage across the parities is folded
+//                        into the M phase's reads.  Every SIMD hosts one whole-row wave and one half-row wave from the start of the phase.
+//                        (Round 1-3: the two rows were cut at their first exchange and handed from waves 2l-2, 2l-1 to waves 2l, 2l+1.)
 //     -- barrier --
 //     M  all 8 waves   : wave w owns points (lane << 3) | w of both accumulator spectra and runs their MAC chains
 //                        over the 2l rows IN ROW ORDER (the reference's fold order), BK values prefetched at step start
 //     -- barrier --
-//     I  waves 0, 1    : inverse transform of component 0 / 1, truncate, += into the LDS accumulator
+//     I  waves 0..3    : (component, parity): each inverse transform on two waves, again split by parity -- a lane reads the eight sums its
+//                        four inputs need and applies the size-2 stage itself, so the waves trade nothing; truncate, += into the LDS accumulator
 //     -- barrier --
 //   key switch: each wave sums the rows of N/8 coefficients, partial sums reduced through LDS.
+// Measured (profiles/r04/latency_parity_split_ab.log, same process, bit-identical): single gate 2.99 -> 2.88 ms (inverse split) -> 2.73 ms (rows
+// split) -> 2.70 ms (half-row waves at priority 1 behind their second exchange).  The F phase is bound by instruction issue per SIMD (about 6.4
+// cycles per instruction for the 800 a whole row plus a half row take): sixteen waves with EVERY row split -- three half rows per SIMD -- finish
+// one after the other and end later (5.7 k cycles against 5.2 k; latency_sixteen_waves_ab.log).
 //
 // Only N = 1024 (R = 8 points per lane = 8 waves for the M phase; LDS 134 KiB).
 #pragma once
