@@ -90,6 +90,11 @@ __device__ __forceinline__ double lds_ld(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #endif
 }
+// ... and one complex value as ONE 16-byte access (ds_write_b128 / ds_read_b128: 13 / 4 LDS cycles against 6 + 6 / 2 + 2 for its two halves, i.e.
+// the same LDS time, in half the instructions -- scripts/ubench/issue_mix.hip: at two waves per SIMD an instruction of any kind costs the SIMD's
+// issue about as much as an FP64 one).  p: 16-byte aligned.
+__device__ __forceinline__ void lds_st128(cplx* p, double re, double im) { *p = make_double2(re, im); }
+__device__ __forceinline__ cplx lds_ld128(const cplx* p) { return *p; }
 
 // ---------------------------------------------------------------------------------------------
 // butterflies (one register-index bit MB at a time; h = 1 << MB; q = m & (h-1) selects the twiddle)
@@ -255,7 +260,9 @@ struct P3 {    // pass 3: register bits LOW-1 .. 0; bits >= 2 twiddled (wave-uni
 // DUAL = true gives the real and the imaginary halves a buffer each (2 x XSLOTS doubles): both are written first and
 // then read back pair by pair in the order the next pass consumes them, so that its first butterflies start while
 // the later reads are still in flight (matters when one wave has the SIMD to itself).
-template <int LOGN, int FROM, int TO, bool DUAL = false>
+// DUAL = 2 (N = 1024 geometry only): the two buffers are ONE array of XSLOTS complex values at xbuf (16-byte aligned; ximbuf unused), every slot one
+// 16-byte access.
+template <int LOGN, int FROM, int TO, int DUAL = 0>
 __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                          double* __restrict__ xbuf, int lane, double* __restrict__ ximbuf = nullptr) {
     typedef Geo<LOGN> G;
@@ -284,6 +291,19 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
         static_assert(G::f1(G::pos1(5, 3)) == 5 + (64 + G::NLOW) * 3 && G::f2(G::pos3(5, 3)) == (R + 1) * 5 + 3, "affine slot maps");
         const int bw = base(FROM), br = base(TO);
         constexpr int sw = stride(FROM), sr = stride(TO);
+        if constexpr (DUAL == 2) {
+            cplx* xc = reinterpret_cast<cplx*>(xbuf);
+#pragma unroll
+            for (int m = 0; m < R; m++) lds_st128(&xc[bw + sw * m], re[m], im[m]);
+            wave_lds_sync();
+#pragma unroll
+            for (int m = 0; m < R / 2; m++) {
+                const cplx a = lds_ld128(&xc[br + sr * m]), b = lds_ld128(&xc[br + sr * (m + R / 2)]);
+                re[m] = a.x; im[m] = a.y; re[m + R / 2] = b.x; im[m + R / 2] = b.y;
+            }
+            wave_lds_sync();
+            return;
+        }
 #ifndef ABL_NOXW
 #pragma unroll
         for (int m = 0; m < R; m++) lds_st(&xbuf[bw + sw * m], re[m]);
@@ -365,7 +385,7 @@ __device__ __forceinline__ void exchange_read_dual(double (&re)[Geo<LOGN>::R], d
 // part A: twist, pass 1, exchange, pass 2.  in: layout L1 (re[m], im[m] = point lane + 64 m), not yet twisted.
 // part B: exchange, pass 3.                  out: layout L3 (point (lane << LR) | m) = the reference's FrrSeries order.
 // tw: LDS, forward table.  xbuf: LDS, wave-private, Geo::XSLOTS doubles.
-template <int LOGN, bool DUAL = false>
+template <int LOGN, int DUAL = 0>
 __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                               const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
                                               double* __restrict__ xim = nullptr) {
@@ -380,7 +400,7 @@ __device__ __forceinline__ void fft_forward_a(double (&re)[Geo<LOGN>::R], double
     exchange<LOGN, 1, 2, DUAL>(re, im, xbuf, lane, xim);
     P12<R, G::LR - 1>::fwd(re, im, w2.w);
 }
-template <int LOGN, bool DUAL = false, bool TRIV = false>
+template <int LOGN, int DUAL = 0, bool TRIV = false>
 __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                               const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
                                               double* __restrict__ xim = nullptr) {
@@ -390,7 +410,7 @@ __device__ __forceinline__ void fft_forward_b(double (&re)[Geo<LOGN>::R], double
     exchange<LOGN, 2, 3, DUAL>(re, im, xbuf, lane, xim);
     P3<G::R, G::NLOW, G::LOW - 1, TRIV>::fwd(re, im, w3.w);
 }
-template <int LOGN, bool DUAL = false, bool TRIV = false>
+template <int LOGN, int DUAL = 0, bool TRIV = false>
 __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                             const cplx* __restrict__ tw, double* __restrict__ xbuf, int lane,
                                             double* __restrict__ xim = nullptr) {
@@ -407,7 +427,7 @@ __device__ __forceinline__ void fft_forward(double (&re)[Geo<LOGN>::R], double (
 // The two halves of the N = 1024 geometry's affine exchange as separate calls (see exchange<>: slot = base(lane) + stride * m), so that a caller
 // can place the 16 writes and the two groups of 8 reads between blocks of arithmetic instead of issuing 32 DS instructions in one burst (a wave's
 // LDS queue holds 16: a burst stalls the wave at issue, and with it its FP64 stream).
-template <int LOGN, int FROM, int TO>
+template <int LOGN, int FROM, int TO, bool B128 = false>
 struct XAffine {
     typedef Geo<LOGN> G;
     static_assert(G::LR == G::LOW, "N = 1024 geometry");
@@ -420,6 +440,12 @@ struct XAffine {
     __device__ __forceinline__ static void write(const double (&re)[R], const double (&im)[R], double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
         const int bw = base(FROM, lane);
         constexpr int sw = stride(FROM);
+        if constexpr (B128) {      // one array of XSLOTS complex values at xbuf (xim unused)
+            cplx* xc = reinterpret_cast<cplx*>(xbuf);
+#pragma unroll
+            for (int m = 0; m < R; m++) lds_st128(&xc[bw + sw * m], re[m], im[m]);
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < R; m++) lds_st(&xbuf[bw + sw * m], re[m]);
 #pragma unroll
@@ -430,6 +456,15 @@ struct XAffine {
     __device__ __forceinline__ static void read_half(double (&re)[R], double (&im)[R], const double* __restrict__ xbuf, const double* __restrict__ xim, int lane) {
         const int br = base(TO, lane);
         constexpr int sr = stride(TO);
+        if constexpr (B128) {
+            const cplx* xc = reinterpret_cast<const cplx*>(xbuf);
+#pragma unroll
+            for (int m = HALF * (R / 4); m < (HALF + 1) * (R / 4); m++) {
+                const cplx a = lds_ld128(&xc[br + sr * m]), b = lds_ld128(&xc[br + sr * (m + R / 2)]);
+                re[m] = a.x; im[m] = a.y; re[m + R / 2] = b.x; im[m + R / 2] = b.y;
+            }
+            return;
+        }
 #pragma unroll
         for (int m = HALF * (R / 4); m < (HALF + 1) * (R / 4); m++) {
             re[m] = lds_ld(&xbuf[br + sr * m]); re[m + R / 2] = lds_ld(&xbuf[br + sr * (m + R / 2)]);
@@ -439,7 +474,7 @@ struct XAffine {
 };
 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook, bool INTERLEAVE = false>
+template <int LOGN, int NR, bool TWIST = true, typename HOOK = NoHook, bool INTERLEAVE = false, bool B128 = false>
 __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::R], double (&im)[NR][Geo<LOGN>::R],
                                                     const cplx* __restrict__ tw, double* __restrict__ xbuf, double* __restrict__ xim, int lane,
                                                     HOOK after_pass1 = HOOK()) {
@@ -467,8 +502,8 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
     // Measured: k_bootstrap_pair 6.73 -> 6.69 ms per 1024 gates; the N = 2048 kernel, whose waves also meet at barriers inside a step, 17.13 -> 17.39
     // (slower): on by template argument where it pays.
     static_assert(G::LR == 3, "three stages per pass");
-    typedef XAffine<LOGN, 1, 2> X1;
-    typedef XAffine<LOGN, 2, 3> X2;
+    typedef XAffine<LOGN, 1, 2, B128> X1;
+    typedef XAffine<LOGN, 2, 3, B128> X2;
     auto pass = [&](int j, const cplx* w, auto&& between0, auto&& between1) {
         fwd_stage_tw<R, 2>(re[j], im[j], w + (R - 8));
         __builtin_amdgcn_sched_barrier(0); between0(); __builtin_amdgcn_sched_barrier(0);
@@ -508,7 +543,7 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             P12<R, G::LR - 1>::fwd(re[j], im[j], w1.w);
-            exchange<LOGN, 1, 2, true>(re[j], im[j], xbuf, lane, xim);
+            exchange<LOGN, 1, 2, B128 ? 2 : 1>(re[j], im[j], xbuf, lane, xim);
         }
     }
     after_pass1();        // a caller's scheduling point (e.g. a priority change) between the two batched passes
@@ -517,7 +552,7 @@ __device__ __forceinline__ void fft_forward_multi_a(double (&re)[NR][Geo<LOGN>::
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         P12<R, G::LR - 1>::fwd(re[j], im[j], w2.w);
-        exchange<LOGN, 2, 3, true>(re[j], im[j], xbuf, lane, xim);
+        exchange<LOGN, 2, 3, B128 ? 2 : 1>(re[j], im[j], xbuf, lane, xim);
     }
   }
 }
@@ -567,7 +602,7 @@ __device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], dou
 // coefficient order: re[m] = coefficient lane + 64 m, im[m] = coefficient lane + 64 m + N/2).
 // tw_small holds the pass-2/3 entries (always LDS), tw_big the pass-1 and untwist entries (LDS, or -- where the LDS
 // budget is better spent on resident gates, N = 2048 -- the global table; both pointers use the per-direction offsets).
-template <int LOGN, bool DUAL = false, bool TRIV = false>
+template <int LOGN, int DUAL = 0, bool TRIV = false>
 __device__ __forceinline__ void fft_inverse(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
                                             const cplx* __restrict__ tw_small, const cplx* __restrict__ tw_big,
                                             double* __restrict__ xbuf, int lane, double* __restrict__ xim = nullptr) {

@@ -49,6 +49,13 @@
 #ifndef PAIR_TRIV
 #define PAIR_TRIV BOOT_TRIV
 #endif
+// the wave-private exchanges of the transforms: 0 = real and imaginary parts as 8-byte accesses of their own, 1 = one 16-byte LDS access per complex
+// value (A/B builds).  Measured (profiles/r04/pair_exchange_16byte_ab.log): SQ_INSTS_LDS 462 M -> 295 M per launch, SQ_LDS_IDX_ACTIVE unchanged
+// (1.53 G: the same LDS-pipe time), no bank conflicts -- and 6.644 -> 6.685 ms per 1024 gates, 4.19 -> 4.27 per 512: the LDS pipe's time is what the
+// exchanges cost, not their instruction slots (and the 16-byte register tuples cost the allocator 21 spilled registers at 4 gates per workgroup).
+#ifndef PAIR_X128
+#define PAIR_X128 0
+#endif
 
 namespace rtfhe {
 
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #ifdef PAIR_NO_INTERLEAVE     // A/B: the exchanges' DS instructions in bursts, as the compiler places them
         fft_forward_multi_a<LOGN, L, true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
 #else
-        fft_forward_multi_a<LOGN, L, true, decltype(pp1), true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
+        fft_forward_multi_a<LOGN, L, true, decltype(pp1), true, PAIR_X128 != 0>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
 #endif
         prio_point(2);
         PAIR_STAMP(1);
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         PAIR_STAMP(8);
 
         // the 2/N input scaling of the reference (fft_processor_spqlios.cpp:158) is folded into the untwist twiddles
-        fft_inverse<LOGN, true, PAIR_TRIV>(sre, sim, twi, twi, myx, lane);
+        fft_inverse<LOGN, PAIR_X128 ? 2 : 1, PAIR_TRIV>(sre, sim, twi, twi, myx, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
