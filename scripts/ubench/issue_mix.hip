@@ -106,6 +106,10 @@ int main() {
     if (run<78, 10, 3, 4, 2, 2, 24, 1, true>("... the same LDS bytes as 16-byte accesses", out, gsrc, cus)) return 1;
     if (run<39, 0, 0, 0, 0, 0, 48>("... its FP64 instructions alone", out, gsrc, cus)) return 1;
     if (run<39, 5, 0, 0, 1, 1, 48>("... without its LDS instructions", out, gsrc, cus)) return 1;
+    if (run<39, 5, 0, 0, 0, 0, 48>("... FP64 + the integer VALU instructions", out, gsrc, cus)) return 1;
+    if (run<39, 0, 0, 0, 1, 0, 48>("... FP64 + the vector-memory instructions", out, gsrc, cus)) return 1;
+    if (run<39, 0, 0, 0, 0, 1, 48>("... FP64 + the scalar instructions", out, gsrc, cus)) return 1;
+    if (run<39, 0, 3, 4, 0, 0, 48>("... FP64 + the LDS instructions", out, gsrc, cus)) return 1;
     // k_bootstrap_eo per wave and step (profiles/r04/pmc_n2048_eo.json / 2): 4,056 FP64, 646 integer VALU, 400 ds_write, 426 ds_read, 142 vmem, 153 salu
     if (run<39, 6, 4, 4, 1, 1, 104>("k_bootstrap_eo's mix (N = 2048)", out, gsrc, cus)) return 1;
     if (run<39, 6, 3, 4, 1, 1, 104, 2>("... one LDS wait per two units, 312 ds_write", out, gsrc, cus)) return 1;
