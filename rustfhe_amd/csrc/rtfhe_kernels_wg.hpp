@@ -23,23 +23,12 @@
 // cycles per instruction for the 800 a whole row plus a half row take): sixteen waves with EVERY row split -- three half rows per SIMD -- finish
 // one after the other and end later (5.7 k cycles against 5.2 k; latency_sixteen_waves_ab.log).
 //
-// Only N = 1024 (R = 8 points per lane = 8 waves for the M phase; LDS 134 KiB).
+// Only N = 1024 (R = 8 points per lane = 8 waves for the M phase; LDS 132 KiB).
 #pragma once
 
 #include "rtfhe_kernels.hpp"
 #include "rtfhe_sub256.hpp"
 
-// the I phase: 1 = each inverse transform on TWO waves, split by the parity of the point index (rtfhe_sub256.hpp; four waves busy, one per SIMD),
-// 0 = one wave per component (A/B builds)
-#ifndef WG_SPLIT_INVERSE
-#define WG_SPLIT_INVERSE 1
-#endif
-// the F phase's last two rows: 1 = each on TWO waves from the start of the phase, split by the parity of the point index (waves 2l-2 .. 2l+1, one per
-// SIMD beside a whole-row wave; the size-2 stage across the parities is folded into the M phase's reads), 0 = cut at the first exchange and handed
-// from waves 2l-2, 2l-1 to waves 2l, 2l+1 (A/B builds)
-#ifndef WG_SPLIT_ROWS
-#define WG_SPLIT_ROWS 1
-#endif
 // priority of the half-row waves during the F phase (they share a SIMD with a whole-row wave each: half the arithmetic, one more LDS round trip)
 #ifndef WG_HALF_PRIO
 #define WG_HALF_PRIO 0
@@ -59,14 +48,17 @@ template <int LOGN, int L>
 struct WgLds {
     typedef Geo<LOGN> G;
     static constexpr int NW = 8;
+    // A spectrum row's slot is XSLOTS complex values wide (P of them the spectrum): the wave that produces the row uses the slot as its exchange
+    // buffer first -- one 16-byte LDS access per complex value (in this latency-bound kernel half the LDS instructions are worth 1.6 % per phase,
+    // profiles/r04/latency_16byte_exchanges_ab.log; in the throughput kernels they are not, see PAIR_X128) -- and the I phase's waves do the same.
+    static constexpr int SROW = G::XSLOTS;
     static constexpr size_t TW = 0;
     static constexpr size_t ACC = TW + (size_t)G::TW_TOTAL * sizeof(cplx);
-    static constexpr size_t SPEC = ACC + (size_t)2 * G::N * 4;                       // cplx[2l][P]  (also key-switch partials)
-    static constexpr size_t SBUF = SPEC + (size_t)2 * L * G::P * sizeof(cplx);       // cplx[2][P]
-    static constexpr size_t XBUF = SBUF + (size_t)2 * G::P * sizeof(cplx);           // double[2l][XSLOTS]
-    static constexpr size_t ABAR = XBUF + (size_t)2 * L * G::XSLOTS * sizeof(double);
-    __host__ __device__ static constexpr size_t flags(int npad) { return ABAR + (size_t)npad * 4; }   // int[2]: hand-off of rows 2l-2, 2l-1
-    __host__ __device__ static constexpr size_t bytes(int npad) { return flags(npad) + 16; }
+    static constexpr size_t SPEC = ACC + (size_t)2 * G::N * 4;                       // cplx[2l][SROW]  (also key-switch partials)
+    static constexpr size_t SBUF = SPEC + (size_t)2 * L * SROW * sizeof(cplx);       // cplx[2][P]
+    static constexpr size_t XBUF = SBUF + (size_t)2 * G::P * sizeof(cplx);           // cplx[4][Q4::XS]: exchange buffers of the half-row waves
+    static constexpr size_t ABAR = XBUF + (size_t)4 * Q4::XS * sizeof(cplx);
+    __host__ __device__ static constexpr size_t bytes(int npad) { return ABAR + (size_t)npad * 4; }
 };
 
 template <int LOGN, int L, int BGBIT, int KS_T, int KS_BB, int KSQ>
@@ -85,15 +77,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     uint32_t* abar = reinterpret_cast<uint32_t*>(smem + S::ABAR);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // row this wave works on in the F phase: waves 2l, 2l+1 take over rows 2l-2, 2l-1 half way (see the F phase)
-    const int frow = wave < ROWS ? wave : wave - 2;
-    double* xbuf = reinterpret_cast<double*>(smem + S::XBUF) + (size_t)frow * G::XSLOTS;
-    volatile int* flags = reinterpret_cast<volatile int*>(smem + S::flags(a.npad));
-    if (tid < 2) flags[tid] = 0;
     const cplx* twf = tw;
-#if !WG_SPLIT_INVERSE
-    const cplx* twi = tw + G::TW_DIR;
-#endif
     const int g = blockIdx.x;                       // grid = count
     const int n = a.n;
 
@@ -156,21 +140,16 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     };
 #endif
     if (a.steps > 0) load_bk(0, bkv);
-#if WG_SPLIT_INVERSE
     // waves 0..3 = (component wave >> 1, parity wave & 1) of the I phase: their 15 twiddles stay in registers over the whole blind rotation
     // (the parity tables ride behind the table staged into LDS above)
     Q4Regs qinv;
-    qinv.load(a.tw + G::TW_TOTAL + Q4Tw::off((WG_SPLIT_ROWS && wave >= 4) ? 0 : 1, wave & 1), lane);      // waves 4..7: the forward tables of their half row
-#endif
+    qinv.load(a.tw + G::TW_TOTAL + Q4Tw::off(wave >= 4 ? 0 : 1, wave & 1), lane);      // waves 4..7: the forward tables of their half row
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
         WG_STAMP(0);
-        // ---- F: one digit polynomial per row (trgsw.rs:269-289).  Six transforms on four SIMDs: rows 0..3 run whole on
-        // waves 0..3 (one per SIMD); rows 4, 5 START on waves 4, 5 (which share SIMDs 0, 1 with waves 0, 1): gather, twist,
-        // pass 1 and the write half of the first exchange, at raised priority -- and FINISH on waves 6, 7 (SIMDs 2, 3):
-        // read half, pass 2, second exchange, pass 3, spectrum store.  The hand-off is a release/acquire flag in LDS.
-#if WG_SPLIT_ROWS
+        // ---- F: one digit polynomial per row (trgsw.rs:269-289).  Six transforms on four SIMDs: rows 0..3 run whole on waves 0..3 (one per SIMD);
+        // rows 4, 5 on waves 4..7 = (row, parity of the point index), one beside every whole-row wave (rtfhe_sub256.hpp).
         if (wave < ROWS - 2) {
             const int h = wave / L, jj = wave - h * L;
             const uint32_t* poly = accbuf + h * N;
@@ -183,10 +162,9 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                 re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
                 im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
             }
-            // second exchange buffer = this row's own (still unwritten) spectrum slot
-            double* xim = reinterpret_cast<double*>(spec + (size_t)wave * P);
-            fft_forward<LOGN, true, BOOT_TRIV>(re, im, twf, xbuf, lane, xim);
-            cplx* dst = spec + (size_t)wave * P + lane;
+            // exchange buffer = this row's own (still unwritten) spectrum slot, one 16-byte access per complex value
+            fft_forward<LOGN, 2, BOOT_TRIV>(re, im, twf, reinterpret_cast<double*>(spec + (size_t)wave * S::SROW), lane);
+            cplx* dst = spec + (size_t)wave * S::SROW + lane;
 #pragma unroll
             for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
         } else {
@@ -195,9 +173,8 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             const int k = wave - (ROWS - 2), row = (ROWS - 2) + (k >> 1);
             const int h = row / L, jj = row - h * L;
             const uint32_t* poly = accbuf + h * N;
-            cplx* half = spec + (size_t)row * P + (k & 1) * (P / 2);
-            double* xre = reinterpret_cast<double*>(sbuf) + k * Q4::XS;        // the sums' buffer is idle until the M phase
-            double* xim = reinterpret_cast<double*>(half);                      // ... and this wave's own, still unwritten, half slot
+            cplx* half = spec + (size_t)row * S::SROW + (k & 1) * (P / 2);
+            cplx* xc = reinterpret_cast<cplx*>(smem + S::XBUF) + (size_t)k * Q4::XS;
             __builtin_amdgcn_s_setprio(WG_HALF_PRIO);
             auto run = [&](auto odd) {
                 constexpr bool ODD = decltype(odd)::value;
@@ -210,52 +187,13 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                     re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
                     im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
                 }
-                sub256_forward<ODD, BOOT_TRIV>(re, im, qinv, xre, xim, lane, [](int k) { if (WG_HALF_PRIO_AT && k == WG_HALF_PRIO_AT) __builtin_amdgcn_s_setprio(WG_HALF_PRIO_THEN); });
+                sub256_forward<ODD, BOOT_TRIV>(re, im, qinv, xc, lane, [](int k) { if (WG_HALF_PRIO_AT && k == WG_HALF_PRIO_AT) __builtin_amdgcn_s_setprio(WG_HALF_PRIO_THEN); });
 #pragma unroll
                 for (int m = 0; m < 4; m++) half[m * 64 + lane] = make_double2(re[m], im[m]);
             };
             if (k & 1) run(std::true_type{}); else run(std::false_type{});
             __builtin_amdgcn_s_setprio(0);
         }
-#else
-        if (wave < ROWS) {
-            const int h = wave / L, jj = wave - h * L;
-            const uint32_t* poly = accbuf + h * N;
-            if (wave >= ROWS - 2) __builtin_amdgcn_s_setprio(3);
-            double re[R], im[R];
-#pragma unroll
-            for (int m = 0; m < R; m++) {
-                const int c0 = lane + 64 * m, c1 = c0 + P;
-                const uint32_t d0 = rotated_coef<LOGN>(poly, c0, r) - poly[c0];
-                const uint32_t d1 = rotated_coef<LOGN>(poly, c1, r) - poly[c1];
-                re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
-                im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
-            }
-            // second exchange buffer = this row's own (still unwritten) spectrum slot
-            double* xim = reinterpret_cast<double*>(spec + (size_t)wave * P);
-            if (wave < ROWS - 2) {
-                fft_forward<LOGN, true, BOOT_TRIV>(re, im, twf, xbuf, lane, xim);
-                cplx* dst = spec + (size_t)wave * P + lane;
-#pragma unroll
-                for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
-            } else {
-                fft_forward_head<LOGN>(re, im, twf, xbuf, xim, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                flags[wave - (ROWS - 2)] = i + 1;
-                __builtin_amdgcn_s_setprio(0);
-            }
-        } else {
-            const int k = wave - ROWS;
-            while (__builtin_amdgcn_readfirstlane(flags[k]) != i + 1) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            double re[R], im[R];
-            double* xim = reinterpret_cast<double*>(spec + (size_t)frow * P);
-            fft_forward_tail<LOGN, BOOT_TRIV>(re, im, twf, xbuf, xim, lane);
-            cplx* dst = spec + (size_t)frow * P + lane;
-#pragma unroll
-            for (int m = 0; m < R; m++) dst[m * 64] = make_double2(re[m], im[m]);
-        }
-#endif
         WG_STAMP(1);
         __syncthreads();
         WG_STAMP(2);
@@ -265,17 +203,13 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             const cplx* src = spec + wave * 64 + lane;
 #pragma unroll
             for (int j = 0; j < ROWS; j++) {
-#if WG_SPLIT_ROWS
                 cplx d;
-                if (j < ROWS - 2) d = src[(size_t)j * P];
+                if (j < ROWS - 2) d = src[(size_t)j * S::SROW];
                 else {      // point 8 lane + wave = 2 jq + (wave & 1), jq = 4 lane + (wave >> 1): out_0[jq] + out_1[jq] or out_0[jq] + (-out_1[jq])
-                    const cplx* hs = spec + (size_t)j * P + (wave >> 1) * 64 + lane;
+                    const cplx* hs = spec + (size_t)j * S::SROW + (wave >> 1) * 64 + lane;
                     const cplx e = hs[0], o = hs[P / 2];
                     d = (wave & 1) ? make_double2(e.x + (-o.x), e.y + (-o.y)) : make_double2(e.x + o.x, e.y + o.y);
                 }
-#else
-                const cplx d = src[(size_t)j * P];
-#endif
                 {
                     const double ii = bkv[j][0].y * d.y, rr = bkv[j][0].x * d.x, ri = bkv[j][0].x * d.y, ir = bkv[j][0].y * d.x;
                     s0r = s0r + (rr - ii);
@@ -295,7 +229,6 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
         WG_STAMP(4);
         cplx bkn[ROWS][2];
         load_bk(i + 1 < a.steps ? i + 1 : i, bkn);
-#if WG_SPLIT_INVERSE
         // ---- I: each component's inverse transform (math.rs:279-288) on two waves, one per parity of the point index; += (trlwe.rs:49-60) ----
         // A lane reads the eight sums s[8 lane .. 8 lane + 7] its parity's four inputs need (both parities read the same words): the size-2 stage
         // across the parities is computed here, in_0[j] = s[2j] + s[2j + 1], in_1[j] = s[2j] + (-s[2j + 1]), j = 4 lane + m -- no trade between the waves.
@@ -306,8 +239,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
 #pragma unroll
             for (int m = 0; m < R; m++) v[m] = src[m * 64];
             // the spectra are dead after the M phase: slot `wave` holds this wave's exchange buffers
-            double* xre = reinterpret_cast<double*>(spec + (size_t)wave * P);
-            double* xim = xre + Q4::XS;
+            cplx* xc = spec + (size_t)wave * S::SROW;
             uint32_t* poly = accbuf + comp * N;
             auto run = [&](auto odd) {
                 constexpr bool ODD = decltype(odd)::value;
@@ -317,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                     re[m] = ODD ? v[2 * m].x + (-v[2 * m + 1].x) : v[2 * m].x + v[2 * m + 1].x;
                     im[m] = ODD ? v[2 * m].y + (-v[2 * m + 1].y) : v[2 * m].y + v[2 * m + 1].y;
                 }
-                sub256_inverse<ODD, BOOT_TRIV>(re, im, qinv, xre, xim, lane);
+                sub256_inverse<ODD, BOOT_TRIV>(re, im, qinv, xc, lane);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const int c = 2 * (lane + 64 * m) + (ODD ? 1 : 0);
@@ -327,24 +259,6 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             };
             if (wave & 1) run(std::true_type{}); else run(std::false_type{});
         }
-#else
-        // ---- I: one accumulator component per wave (math.rs:279-288; trlwe.rs:49-60 for the += ) ----
-        if (wave < 2) {
-            double re[R], im[R];
-            const cplx* src = sbuf + (size_t)wave * P + lane;
-#pragma unroll
-            for (int m = 0; m < R; m++) { const cplx v = src[m * 64]; re[m] = v.x; im[m] = v.y; }
-            // the spectra are dead after the M phase: slot `wave` serves as the second exchange buffer
-            fft_inverse<LOGN, true, BOOT_TRIV>(re, im, twi, twi, xbuf, lane, reinterpret_cast<double*>(spec + (size_t)wave * P));
-            uint32_t* poly = accbuf + wave * N;
-#pragma unroll
-            for (int m = 0; m < R; m++) {
-                const int c = lane + 64 * m;
-                poly[c] += trunc_to_torus(re[m]);
-                poly[c + P] += trunc_to_torus(im[m]);
-            }
-        }
-#endif
         WG_STAMP(5);
         __syncthreads();
         WG_STAMP(6);

@@ -54,10 +54,10 @@ struct Q4Regs {
 };
 struct Q4 {
     static constexpr int R = 4;
-    static constexpr int XS = 320;               // doubles per plane of an exchange buffer (the largest padded slot is 318)
+    static constexpr int XS = 320;               // complex slots of an exchange buffer (the largest padded slot is 318); 16-byte aligned
     // Slot of register m in the buffer of the exchange between layouts X and X + 1: base(lane) + stride * m, with the pads
     //   L1 <-> L2: slot(j) = j + 16 (j >> 6)     L2 <-> L3: j + 4 (j >> 4)     L3 <-> L4: j + (j >> 2)
-    // chosen so that the 32 lanes of a half-wave hit 32 different 8-byte bank pairs on the write AND on the read side.
+    // chosen conflict-free on the write AND on the read side.
     template <int X, int LAYOUT>
     __device__ __forceinline__ static int base(int lane) {
         if constexpr (X == 1) return LAYOUT == 1 ? lane : 80 * (lane >> 4) + (lane & 15);
@@ -68,21 +68,20 @@ struct Q4 {
     __host__ __device__ static constexpr int stride() {
         return X == 1 ? (LAYOUT == 1 ? 80 : 16) : X == 2 ? (LAYOUT == 2 ? 20 : 4) : (LAYOUT == 3 ? 5 : 1);
     }
+    // one 16-byte LDS access per complex value
     template <int FROM, int TO>
-    __device__ __forceinline__ static void exchange(double (&re)[R], double (&im)[R], double* __restrict__ xre, double* __restrict__ xim, int lane) {
+    __device__ __forceinline__ static void exchange(double (&re)[R], double (&im)[R], cplx* __restrict__ xc, int lane) {
         constexpr int X = FROM < TO ? FROM : TO;
         static_assert(FROM + TO == 2 * X + 1, "neighbouring layouts");
         const int bw = base<X, FROM>(lane), br = base<X, TO>(lane);
         constexpr int sw = stride<X, FROM>(), sr = stride<X, TO>();
 #pragma unroll
-        for (int m = 0; m < R; m++) lds_st(&xre[bw + sw * m], re[m]);
-#pragma unroll
-        for (int m = 0; m < R; m++) lds_st(&xim[bw + sw * m], im[m]);
+        for (int m = 0; m < R; m++) lds_st128(&xc[bw + sw * m], re[m], im[m]);
         wave_lds_sync();
 #pragma unroll
         for (int m = 0; m < R / 2; m++) {        // the next pass's first stage pairs m with m + 2
-            re[m] = lds_ld(&xre[br + sr * m]); re[m + 2] = lds_ld(&xre[br + sr * (m + 2)]);
-            im[m] = lds_ld(&xim[br + sr * m]); im[m + 2] = lds_ld(&xim[br + sr * (m + 2)]);
+            const cplx a = lds_ld128(&xc[br + sr * m]), b = lds_ld128(&xc[br + sr * (m + 2)]);
+            re[m] = a.x; im[m] = a.y; re[m + 2] = b.x; im[m + 2] = b.y;
         }
         wave_lds_sync();
     }
@@ -92,22 +91,21 @@ struct Q4 {
 // i.e. what the size-2 stage across the parities still has to combine (spectrum point 2 j = out_0[j] + out_1[j], 2 j + 1 = out_0[j] + (-out_1[j])).
 struct Q4NoHook { __device__ __forceinline__ void operator()(int) const {} };
 template <bool ODD, bool TRIV, typename W, typename HOOK = Q4NoHook>
-__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const W& w, double* __restrict__ xre, double* __restrict__ xim, int lane,
-                                               HOOK after_exchange = HOOK()) {
+__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane, HOOK after_exchange = HOOK()) {
     cplx wt[4], w1[3], w2[3], w3[3], w4[2];
     w.get_wt(wt); w.get_w1(w1);
     twist_mul<4>(re, im, wt);
     P12<4, 1>::fwd(re, im, w1);
     w.get_w2(w2);
-    Q4::exchange<1, 2>(re, im, xre, xim, lane);
+    Q4::exchange<1, 2>(re, im, xc, lane);
     after_exchange(1);
     P12<4, 1>::fwd(re, im, w2);
     w.get_w3(w3);
-    Q4::exchange<2, 3>(re, im, xre, xim, lane);
+    Q4::exchange<2, 3>(re, im, xc, lane);
     after_exchange(2);
     P12<4, 1>::fwd(re, im, w3);
     w.get_w4(w4);
-    Q4::exchange<3, 4>(re, im, xre, xim, lane);
+    Q4::exchange<3, 4>(re, im, xc, lane);
     after_exchange(3);
     fwd_stage_tw<4, 1, TRIV && !ODD>(re, im, w4);       // i-halfnn 4; entry 0 of parity 0 is the reference's (1, 0): see fwd_stage_tw
     // this parity's half of the size-4 stage (spqlios-fft-impl.cpp:581-602): even points x0, x2 -> x0 + x2, x0 + (-x2); odd points x1, x3 ->
@@ -123,7 +121,7 @@ __device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4],
 // Inverse: in = in_H[j] in layout L4 (the size-2 stage across the parities already applied: in_0[j] = s[2j] + s[2j + 1], in_1[j] = s[2j] + (-s[2j + 1]));
 // out = this parity's coefficients, untwisted (the 2/N of fft_processor_spqlios.cpp:158 is in the table), layout L1.
 template <bool ODD, bool TRIV, typename W>
-__device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4], const W& w, double* __restrict__ xre, double* __restrict__ xim, int lane) {
+__device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane) {
     cplx wt[4], w1[3], w2[3], w3[3], w4[2];
     w.get_w4(w4); w.get_w3(w3);
     // this parity's half of the size-4 stage (:289-310): even x0, x2 -> x0 + x2, x0 + (-x2); odd x1, x3 -> x1 - i x3 = (r1 + j3, j1 + (-r3)),
@@ -135,13 +133,13 @@ __device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4],
         else      { re[m] = ra + jb; re[m + 1] = ra + (-jb); im[m] = ja + (-rb); im[m + 1] = ja + rb; }
     }
     inv_stage_tw<4, 1, false, TRIV && !ODD>(re, im, w4);
-    Q4::exchange<4, 3>(re, im, xre, xim, lane);
+    Q4::exchange<4, 3>(re, im, xc, lane);
     P12<4, 1>::inv(re, im, w3);
     w.get_w2(w2);
-    Q4::exchange<3, 2>(re, im, xre, xim, lane);
+    Q4::exchange<3, 2>(re, im, xc, lane);
     P12<4, 1>::inv(re, im, w2);
     w.get_w1(w1); w.get_wt(wt);
-    Q4::exchange<2, 1>(re, im, xre, xim, lane);
+    Q4::exchange<2, 1>(re, im, xc, lane);
     P12<4, 1>::inv(re, im, w1);
     twist_mul<4>(re, im, wt);
 }
