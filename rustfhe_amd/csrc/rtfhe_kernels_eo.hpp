@@ -44,6 +44,9 @@
 #ifndef EO_COMP_COPIES
 #define EO_COMP_COPIES 0
 #endif
+#ifndef EO_DS_ADD
+#define EO_DS_ADD 1
+#endif
 // (The accumulator as two parity planes per polynomial in LDS -- coefficient c at word 1024 (c & 1) + (c >> 1), so that a wave's gather and update touch
 // consecutive words instead of every second one -- removes the gather's 2-way bank conflicts (0.33 G conflict cycles per 1024-gate launch) and
 // measured +-0 to +1.4 %: 15.27 -> 15.34 ms per 1024 gates, 13.20 -> 13.39 per 768; the compiler's address arithmetic for it is two integer
@@ -438,8 +441,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
                     // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395); the 2/N of fft_processor_spqlios.cpp:158 is in the table
                     const double rc = vr * wt.w[m].x, ic = vi * wt.w[m].x, rs = vr * wt.w[m].y, is = vi * wt.w[m].y;
                     const int c = 2 * (lane + 64 * m) + H;
+#if EO_DS_ADD         // the update as ds_add_u32: no read-back through the wave (14.59 -> 14.52 ms per 1024 gates, 9.98 -> 9.91 per 512; the latency kernel, whose
+                      // lone waves wait on the add's completion, loses 2 % with it)
+                    __hip_atomic_fetch_add(&poly[c], trunc_to_torus(rc - is), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&poly[c + P], trunc_to_torus(ic + rs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
                     poly[c] += trunc_to_torus(rc - is);
                     poly[c + P] += trunc_to_torus(ic + rs);
+#endif
                 }
             }
             // (my accumulator words are published by my next arrival -- the other component's trade / the next step's first row -- which the
