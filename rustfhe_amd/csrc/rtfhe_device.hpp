@@ -349,38 +349,6 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
     }
 }
 
-// The two halves of exchange<.., DUAL = true> as separate calls: one wave may write and ANOTHER read (after a release /
-// acquire hand-off of its own); xbuf and xim hold Geo::XSLOTS doubles each.
-template <int LOGN, int FROM, int TO>
-__device__ __forceinline__ void exchange_write_dual(const double (&re)[Geo<LOGN>::R], const double (&im)[Geo<LOGN>::R],
-                                                    double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
-    typedef Geo<LOGN> G;
-    constexpr int R = G::R;
-    auto slot = [&](int m) {
-        const int pos = FROM == 1 ? G::pos1(lane, m) : FROM == 2 ? G::pos2(lane, m) : G::pos3(lane, m);
-        return (FROM + TO == 3) ? G::f1(pos) : G::f2(pos);
-    };
-#pragma unroll
-    for (int m = 0; m < R; m++) lds_st(&xbuf[slot(m)], re[m]);
-#pragma unroll
-    for (int m = 0; m < R; m++) lds_st(&xim[slot(m)], im[m]);
-}
-template <int LOGN, int FROM, int TO>
-__device__ __forceinline__ void exchange_read_dual(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R],
-                                                   const double* __restrict__ xbuf, const double* __restrict__ xim, int lane) {
-    typedef Geo<LOGN> G;
-    constexpr int R = G::R;
-    auto slot = [&](int m) {
-        const int pos = TO == 1 ? G::pos1(lane, m) : TO == 2 ? G::pos2(lane, m) : G::pos3(lane, m);
-        return (FROM + TO == 3) ? G::f1(pos) : G::f2(pos);
-    };
-#pragma unroll
-    for (int m = 0; m < R / 2; m++) {
-        re[m] = lds_ld(&xbuf[slot(m)]); re[m + R / 2] = lds_ld(&xbuf[slot(m + R / 2)]);
-        im[m] = lds_ld(&xim[slot(m)]);  im[m + R / 2] = lds_ld(&xim[slot(m + R / 2)]);
-    }
-}
-
 // Forward transform in two parts so that a caller can issue global loads between them.
 // part A: twist, pass 1, exchange, pass 2.  in: layout L1 (re[m], im[m] = point lane + 64 m), not yet twisted.
 // part B: exchange, pass 3.                  out: layout L3 (point (lane << LR) | m) = the reference's FrrSeries order.
@@ -564,38 +532,6 @@ __device__ __forceinline__ void fft_forward_multi_b(double (&re)[NR][Geo<LOGN>::
     w3.load(tw + G::TW_P3, 1);
 #pragma unroll
     for (int j = 0; j < NR; j++) P3<G::R, G::NLOW, G::LOW - 1, TRIV>::fwd(re[j], im[j], w3.w);
-}
-
-// The forward transform cut at its first exchange, for two waves: head = twist, pass 1, write half of the exchange (into
-// xbuf / xim); tail = read half, pass 2, second exchange, pass 3.  Between them the caller hands the buffers over.
-template <int LOGN>
-__device__ __forceinline__ void fft_forward_head(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
-                                                 double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
-    typedef Geo<LOGN> G;
-    constexpr int R = G::R;
-    Tw<R> wt; Tw<R - 1> w1;
-    wt.load(tw + G::TW_TWIST + lane, 64);
-    w1.load(tw + G::TW_P1 + lane, 64);
-    twist_mul<R>(re, im, wt.w);
-    P12<R, G::LR - 1>::fwd(re, im, w1.w);
-    exchange_write_dual<LOGN, 1, 2>(re, im, xbuf, xim, lane);
-}
-template <int LOGN>
-__device__ __forceinline__ void fft_forward_mid(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
-                                                double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
-    typedef Geo<LOGN> G;
-    constexpr int R = G::R;
-    Tw<R - 1> w2;
-    w2.load(tw + G::TW_P2 + (lane & (G::NLOW - 1)), G::NLOW);
-    exchange_read_dual<LOGN, 1, 2>(re, im, xbuf, xim, lane);
-    wave_lds_sync();
-    P12<R, G::LR - 1>::fwd(re, im, w2.w);
-}
-template <int LOGN, bool TRIV = false>
-__device__ __forceinline__ void fft_forward_tail(double (&re)[Geo<LOGN>::R], double (&im)[Geo<LOGN>::R], const cplx* __restrict__ tw,
-                                                 double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
-    fft_forward_mid<LOGN>(re, im, tw, xbuf, xim, lane);
-    fft_forward_b<LOGN, true, TRIV>(re, im, tw, xbuf, lane, xim);
 }
 
 // Inverse transform.  in: layout L3, unscaled (the 2/N factor lives in the untwist twiddles).  out: layout L1, untwisted (natural
