@@ -21,6 +21,7 @@
 #include "rtfhe_kernels_pair.hpp"
 #include "rtfhe_kernels_halves.hpp"
 #include "rtfhe_kernels_eo.hpp"
+#include "rtfhe_kernels_eo4.hpp"
 #include "rtfhe_kernels_ntt.hpp"
 #include "rtfhe_kernels_ntt_halves.hpp"
 #include "rtfhe_kernels_anyn.hpp"
@@ -294,6 +295,7 @@ struct rtfhe_ctx {
     cplx* d_etw = nullptr;            // N = 2048: tables of k_bootstrap_eo
     cplx* d_ebk = nullptr;            // N = 2048: key spectra in the even / odd layout
     unsigned long long tune = 0;      // tuning builds only (rtfhe_debug_set_tune): handed to the kernels as BootstrapArgs::tune
+    int eo4 = 1;                      // N = 2048, up to two gates per CU: 1 = four waves per gate (k_bootstrap_eo4), 0 = two (RTFHE_N2048_EO4)
     int n2048_kernel = -1;            // -1 = by launch shape (below), 0 = parity split (k_bootstrap_eo), 1 = top-bit split (k_bootstrap_halves);
                                       // RTFHE_N2048_KERNEL=eo|halves
     int backend = RTFHE_BACKEND_FFT64_MIRROR;
@@ -537,8 +539,23 @@ int launch_bootstrap_eo11_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     ctx->launches++;
     return 0;
 }
+// four waves per gate, (polynomial, parity): batches of up to two gates per CU (rtfhe_kernels_eo4.hpp); no fused key switch
+template <int GATES>
+int launch_bootstrap_eo4_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_eo4<3, 6, GATES>;
+    const size_t lds = Eo4Lds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    EoArgs a{b, ctx->d_etw, ctx->d_ebk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(256 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
 template <int GATES>
 int launch_bootstrap_n2048_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    if constexpr (GATES <= 2) {
+        if (ctx->n2048_kernel < 0 && ctx->eo4 && (b.mode == MODE_EXTRACT || b.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_eo4_g<GATES>(ctx, b, s);
+    }
     // Measured (profiles/r04/n2048_parity_split_ab.log, same process, identical outputs): the parity split is faster at every launch shape --
     // 4-10 % where a workgroup holds 1-2 gates (its trades are covered by arithmetic), 1.3 % at 4 gates per workgroup once its priority raise
     // sits inside the wait's assembly statement (no spills), level at 3.  RTFHE_N2048_KERNEL=halves keeps the top-bit split selectable.
@@ -993,6 +1010,8 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 3>, EoLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 2>, EoLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_eo<3, 6, 8, 2, KSQ, 1>, EoLds::bytes(1, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_eo4<3, 6, 2>, Eo4Lds::bytes(2, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_eo4<3, 6, 1>, Eo4Lds::bytes(1, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_halves<3, 6, 8, 2, KSQ, 4>, NttHalvesLds::bytes(4, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_halves<3, 6, 8, 2, KSQ, 3>, NttHalvesLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_halves<3, 6, 8, 2, KSQ, 2>, NttHalvesLds::bytes(2, npad))) return rc;
@@ -1139,6 +1158,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
         if (const char* e = std::getenv("RTFHE_WG_MAX_GATES")) ctx->wg_max = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_STAGING")) ctx->stage_pinned = std::atoi(e) != 0;
         if (const char* e = std::getenv("RTFHE_KS_MM_MIN")) ctx->ks_mm_min = std::atoi(e);
+        if (const char* e = std::getenv("RTFHE_N2048_EO4")) ctx->eo4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("RTFHE_N2048_KERNEL")) ctx->n2048_kernel = std::string(e) == "halves" ? 1 : std::string(e) == "eo" ? 0 : -1;
     }
     if (!rc) rc = prime_kernel_attributes(ctx);
