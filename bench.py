@@ -534,6 +534,13 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
             sec["config5_n2048_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3),
                                                "kernel": "k_bootstrap_halves" if top_bit else "k_bootstrap_eo",
                                                "dp_wave_instr_per_cmux": ops5, "roofline_frac_fp64": fp64_frac(ops5, p5.n, G, ms * 1e-3), "ok": ok5}
+            # below a full round (the library's default: four waves per gate, k_bootstrap_eo4, at up to two gates per CU): 3 launches each
+            small = {}
+            for gs in (1, 256, 512):
+                ms_s, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xo, gs, stream), 3)
+                ok_s = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)[:gs]), (1 - (bb[0] & bb[1]))[:gs]))
+                small[str(gs)] = {"ms_per_launch": round(ms_s, 3), "gates_per_s": round(gs / ms_s * 1e3, 1), "ok": ok_s}
+            sec["config5_n2048_small_batches"] = small
         finally:
             e5.close()
     guard("config5_n2048_1024_gates", _config5_n2048_1024_gates)

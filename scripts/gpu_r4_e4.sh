@@ -1,10 +1,7 @@
 #!/bin/bash
-# round 4: k_bootstrap_eo4 (N = 2048, four waves per gate) against k_bootstrap_eo at up to two gates per CU, same library, RTFHE_N2048_EO4 per context
 set -o pipefail
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/r4e4; mkdir -p $O
-LIB=rustfhe_amd/librtfhe_hip.so
-for g in 1 256 300 512 768; do
-  echo "== N=2048 gates=$g" | tee -a $O/ab_eo4.log
-  RTFHE_N=2048 timeout -k 10 120 python scripts/ab_libs.py $g 5 $LIB:RTFHE_N2048_EO4=0 $LIB:RTFHE_N2048_EO4=1 2>&1 | grep -v amdgpu.ids | tee -a $O/ab_eo4.log || exit 1
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_soak.py -m gpu -x -q 2>&1 | tail -3 | tee $O/pytest2.log &&
+timeout -k 10 500 python bench.py --no-cpu-baseline > $O/bench_nocpu.json 2> $O/bench.err; echo "bench rc=$?"; python3 -c "
+import json; d=json.loads(open('$O/bench_nocpu.json').read().strip().splitlines()[-1]); print(d['value'], d['secondary']['config5_n2048_1024_gates']['gates_per_s'], d['secondary']['config5_n2048_small_batches'])"

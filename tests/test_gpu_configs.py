@@ -280,10 +280,11 @@ def test_key_file_feeds_an_engine(tmp_path, params, keys, gold_gate):
 
 @pytest.mark.parametrize("other", ["one_wave_per_gate", "top_bit_split", "parity_split"])
 def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch, other):
-    """N = 2048: the default dispatch (two waves per transform: split by the parity of the point index, k_bootstrap_eo, at 1-2 gates per
-    workgroup; by the top index bit, k_bootstrap_halves, at 3-4) against the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4) and against each
-    split forced for every shape (RTFHE_N2048_KERNEL) -- the same arithmetic: identical words for a ragged batch, for blind-rotate prefixes
-    (both compared with the oracle above) and for every launch shape."""
+    """N = 2048: the default dispatch (transforms split over two waves by the parity of the point index: k_bootstrap_eo4, four waves per gate, for
+    up to two gates per CU -- the ragged 37-gate batch, the blind-rotate prefixes and the 257-gate shape below run on it -- and k_bootstrap_eo, two
+    waves per gate, beyond) against the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4) and against each two-wave split forced for every shape
+    (RTFHE_N2048_KERNEL=eo: the parity split, =halves: the split by the top index bit) -- the same arithmetic: identical words for a ragged batch,
+    for blind-rotate prefixes (both compared with the oracle above) and for every launch shape."""
     import rustfhe_amd as R
     P, K, e = setup2048
     rng = np.random.default_rng(2048)
@@ -307,7 +308,7 @@ def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch, other):
         bb0, bb1 = rng.integers(0, 2, 1030), rng.integers(0, 2, 1030)
         d0, d1 = K.encrypt_bits(bb0), K.encrypt_bits(bb1)
         ref = one.gate_batch(R.NAND, d0, d1)
-        for k in (257, 513, 770, 1030):
+        for k in (1, 2, 257, 511, 513, 770, 1030):
             assert np.array_equal(e.gate_batch(R.NAND, d0[:k], d1[:k]), ref[:k]), k
     finally:
         one.close()
