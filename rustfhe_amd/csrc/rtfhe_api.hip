@@ -553,6 +553,8 @@ int launch_bootstrap_eo4_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
 }
 template <int GATES>
 int launch_bootstrap_n2048_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    // up to two gates per CU: four waves per gate, so that no SIMD is left with a lone wave (single gate 9.78 -> 5.84 ms, 512 gates 9.91 -> 7.8 ms,
+    // profiles/r04/n2048_four_waves_per_gate_ab.log); the fused key switch and a forced split stay on the two-wave kernels
     if constexpr (GATES <= 2) {
         if (ctx->n2048_kernel < 0 && ctx->eo4 && (b.mode == MODE_EXTRACT || b.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_eo4_g<GATES>(ctx, b, s);
     }
