@@ -19,6 +19,7 @@
 #include "rtfhe_kernels.hpp"
 #include "rtfhe_kernels_wg.hpp"
 #include "rtfhe_kernels_pair.hpp"
+#include "rtfhe_kernels_pair4.hpp"
 #include "rtfhe_kernels_halves.hpp"
 #include "rtfhe_kernels_eo.hpp"
 #include "rtfhe_kernels_eo4.hpp"
@@ -294,6 +295,8 @@ struct rtfhe_ctx {
     cplx* d_hbk = nullptr;            // N = 2048: key spectra in the halves layout
     cplx* d_etw = nullptr;            // N = 2048: tables of k_bootstrap_eo
     cplx* d_ebk = nullptr;            // N = 2048: key spectra in the even / odd layout
+    cplx* d_p4bk = nullptr;           // N = 1024: key spectra in the layout of k_bootstrap_pair4
+    int pair4 = 1;                    // N = 1024, batches and tails of more than wg_max and up to two gates per CU: 1 = four waves per gate (RTFHE_PAIR4)
     unsigned long long tune = 0;      // tuning builds only (rtfhe_debug_set_tune): handed to the kernels as BootstrapArgs::tune
     int eo4 = 1;                      // N = 2048, up to two gates per CU: 1 = four waves per gate (k_bootstrap_eo4), 0 = two (RTFHE_N2048_EO4)
     int n2048_kernel = -1;            // -1 = by launch shape (below), 0 = parity split (k_bootstrap_eo), 1 = top-bit split (k_bootstrap_halves);
@@ -513,6 +516,18 @@ int launch_bootstrap_pair10_g(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return 0;
 }
 int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return launch_bootstrap_pair10_g<4>(ctx, a, s); }
+// four waves per gate, (polynomial, parity): up to two gates per CU (rtfhe_kernels_pair4.hpp); no fused key switch
+template <int GATES>
+int launch_bootstrap_pair4_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_pair4<3, 6, GATES>;
+    const size_t lds = Pair4Lds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    Pair4Args a{b, ctx->d_p4bk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(256 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
 
 // N = 2048: two waves per transform (rtfhe_kernels_halves.hpp)
 template <int GATES>
@@ -604,8 +619,14 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
             if (int rc = launch_bootstrap_pair10(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
         if (rem) {
             const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
-            if (rem <= (size_t)ctx->wg_max) return launch_bootstrap_wg10(ctx, tail, s);
-            if (rem <= (size_t)2 * ctx->num_cus) return launch_bootstrap_pair10_g<2>(ctx, tail, s);
+            if (rem <= (size_t)ctx->wg_max) {
+                if (ctx->pair4 == 2 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<1>(ctx, tail, s);     // A/B: RTFHE_PAIR4=2
+                return launch_bootstrap_wg10(ctx, tail, s);
+            }
+            if (rem <= (size_t)2 * ctx->num_cus) {
+                if (ctx->pair4 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<2>(ctx, tail, s);
+                return launch_bootstrap_pair10_g<2>(ctx, tail, s);
+            }
             if (rem <= (size_t)3 * ctx->num_cus) return launch_bootstrap_pair10_g<3>(ctx, tail, s);
             return launch_bootstrap_pair10(ctx, tail, s);
         }
@@ -943,6 +964,15 @@ int upload_twiddles(rtfhe_ctx* ctx) {
 
 // N = 2048: the key spectra once more in the layout of k_bootstrap_halves (derived from d_bk on this context's device)
 int build_halves_bk(rtfhe_ctx* ctx) {
+    if (ctx->logn == 10 && ctx->d_bk) {      // N = 1024: the key spectra once more in the layout of k_bootstrap_pair4
+        HIPCHECK(ctx, hipSetDevice(ctx->device));
+        const size_t polys10 = bk_word_count(ctx->p) / ctx->p.N;
+        if (!ctx->d_p4bk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_p4bk, bk_cplx_count(ctx->p) * sizeof(cplx)));
+        hipLaunchKernelGGL(k_bk_to_p4, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, ctx->d_p4bk, polys10);
+        HIPCHECK(ctx, hipGetLastError());
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
     if (ctx->logn != 11 || !ctx->d_bk) return 0;
     HIPCHECK(ctx, hipSetDevice(ctx->device));
     const size_t polys = bk_word_count(ctx->p) / ctx->p.N;
@@ -994,6 +1024,8 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 3>, PairLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 2>, PairLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_wg<10, 3, 6, 8, 2, KSQ>, WgLds<10, 3>::bytes(npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 2>, Pair4Lds::bytes(2, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 1>, Pair4Lds::bytes(1, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<10>(4, npad, bootstrap_dual_xbuf(10, 4)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 8>, bootstrap_lds_bytes<10>(8, npad, bootstrap_dual_xbuf(10, 8)))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_ntt_pair<3, 6, 8, 2, KSQ, 4>, NttPairLds::bytes(4, npad))) return rc;
@@ -1161,6 +1193,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
         if (const char* e = std::getenv("RTFHE_STAGING")) ctx->stage_pinned = std::atoi(e) != 0;
         if (const char* e = std::getenv("RTFHE_KS_MM_MIN")) ctx->ks_mm_min = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_N2048_EO4")) ctx->eo4 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("RTFHE_PAIR4")) ctx->pair4 = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_N2048_KERNEL")) ctx->n2048_kernel = std::string(e) == "halves" ? 1 : std::string(e) == "eo" ? 0 : -1;
     }
     if (!rc) rc = prime_kernel_attributes(ctx);
@@ -1257,6 +1290,7 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_hbk) (void)hipFree(ctx->d_hbk);
     if (ctx->d_etw) (void)hipFree(ctx->d_etw);
     if (ctx->d_ebk) (void)hipFree(ctx->d_ebk);
+    if (ctx->d_p4bk) (void)hipFree(ctx->d_p4bk);
     if (ctx->d_bk_torus) (void)hipFree(ctx->d_bk_torus);
     if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
     if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);

@@ -90,9 +90,11 @@ struct Q4 {
 // Forward: in = this parity's points in layout L1 (digits, not yet twisted); out = the sub-network's outputs out_H[j] in layout L4,
 // i.e. what the size-2 stage across the parities still has to combine (spectrum point 2 j = out_0[j] + out_1[j], 2 j + 1 = out_0[j] + (-out_1[j])).
 struct Q4NoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <bool ODD, bool TRIV, typename W, typename HOOK = Q4NoHook>
-__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane, HOOK after_exchange = HOOK()) {
-    cplx wt[4], w1[3], w2[3], w3[3], w4[2];
+// part A: twist and the three passes that need the exchange buffer; part B: the last pass, registers only (a caller with several rows and one
+// buffer runs A for all of them first)
+template <typename W, typename HOOK = Q4NoHook>
+__device__ __forceinline__ void sub256_forward_a(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane, HOOK after_exchange = HOOK()) {
+    cplx wt[4], w1[3], w2[3], w3[3];
     w.get_wt(wt); w.get_w1(w1);
     twist_mul<4>(re, im, wt);
     P12<4, 1>::fwd(re, im, w1);
@@ -104,9 +106,28 @@ __device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4],
     Q4::exchange<2, 3>(re, im, xc, lane);
     after_exchange(2);
     P12<4, 1>::fwd(re, im, w3);
-    w.get_w4(w4);
     Q4::exchange<3, 4>(re, im, xc, lane);
     after_exchange(3);
+}
+// ... for NR rows side by side, pass by pass: a row's exchange is in flight while the other rows compute (DS instructions of a wave execute in
+// order, so the rows share the buffer back to back), and every pass loads nothing (the twiddles are the caller's registers)
+template <int NR, typename W>
+__device__ __forceinline__ void sub256_forward_a_multi(double (&re)[NR][4], double (&im)[NR][4], const W& w, cplx* __restrict__ xc, int lane) {
+    cplx wt[4], w1[3], w2[3], w3[3];
+    w.get_wt(wt); w.get_w1(w1);
+#pragma unroll
+    for (int j = 0; j < NR; j++) { twist_mul<4>(re[j], im[j], wt); P12<4, 1>::fwd(re[j], im[j], w1); Q4::exchange<1, 2>(re[j], im[j], xc, lane); }
+    w.get_w2(w2);
+#pragma unroll
+    for (int j = 0; j < NR; j++) { P12<4, 1>::fwd(re[j], im[j], w2); Q4::exchange<2, 3>(re[j], im[j], xc, lane); }
+    w.get_w3(w3);
+#pragma unroll
+    for (int j = 0; j < NR; j++) { P12<4, 1>::fwd(re[j], im[j], w3); Q4::exchange<3, 4>(re[j], im[j], xc, lane); }
+}
+template <bool ODD, bool TRIV, typename W>
+__device__ __forceinline__ void sub256_forward_b(double (&re)[4], double (&im)[4], const W& w) {
+    cplx w4[2];
+    w.get_w4(w4);
     fwd_stage_tw<4, 1, TRIV && !ODD>(re, im, w4);       // i-halfnn 4; entry 0 of parity 0 is the reference's (1, 0): see fwd_stage_tw
     // this parity's half of the size-4 stage (spqlios-fft-impl.cpp:581-602): even points x0, x2 -> x0 + x2, x0 + (-x2); odd points x1, x3 ->
     // x1 + x3, i (x1 - x3) = ((-j1) + j3, r1 + (-r3))
@@ -116,6 +137,11 @@ __device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4],
         if (!ODD) { re[m] = ra + rb; re[m + 1] = ra + (-rb); im[m] = ja + jb; im[m + 1] = ja + (-jb); }
         else      { re[m] = ra + rb; re[m + 1] = (-ja) + jb; im[m] = ja + jb; im[m + 1] = ra + (-rb); }
     }
+}
+template <bool ODD, bool TRIV, typename W, typename HOOK = Q4NoHook>
+__device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane, HOOK after_exchange = HOOK()) {
+    sub256_forward_a(re, im, w, xc, lane, after_exchange);
+    sub256_forward_b<ODD, TRIV>(re, im, w);
 }
 
 // Inverse: in = in_H[j] in layout L4 (the size-2 stage across the parities already applied: in_0[j] = s[2j] + s[2j + 1], in_1[j] = s[2j] + (-s[2j + 1]));

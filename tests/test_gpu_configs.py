@@ -74,6 +74,36 @@ def test_config3_whole_batch_65536_on_one_gpu(engine, orc, params, keys):
     assert np.array_equal(out[pick], exp)
 
 
+def test_four_waves_per_gate_agree_with_two_at_n1024(engine, orc, params, keys, monkeypatch):
+    """N = 1024, batches and tails of more than 256 and up to 512 gates: the default dispatch gives a gate four waves -- (polynomial, parity of the
+    point index), k_bootstrap_pair4 -- where RTFHE_PAIR4=0 keeps k_bootstrap_pair's two: the same arithmetic, so identical words for whole gates,
+    for a tail behind a full round, and for blind-rotation prefixes (the latter also against the oracle)."""
+    import rustfhe_amd as R
+    rng = np.random.default_rng(44)
+    G = 1024 + 300
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+    monkeypatch.setenv("RTFHE_PAIR4", "0")
+    two = R.Engine(R.Params(n=params.n, N=params.N, l=params.l, bgbit=params.bgbit, ks_t=params.ks_t, ks_basebit=params.ks_basebit), 0)
+    monkeypatch.delenv("RTFHE_PAIR4")
+    try:
+        two.load_bk_torus(keys.bk_t)
+        two.load_ksk(keys.ksk)
+        ref = two.gate_batch(R.NAND, c0, c1)
+        for k in (257, 300, 511, 512, G):
+            out = engine.gate_batch(R.NAND, c0[:k], c1[:k])
+            assert np.array_equal(out, ref[:k]), k
+        assert keys.decrypt_bits(engine.gate_batch(R.XOR, c0[:400], c1[:400])) == list(b0[:400] ^ b1[:400])
+        t = np.stack([orc.gate_linear(params, orc.NAND, x, y) for x, y in zip(c0[:260], c1[:260])])
+        pl = orc.Plan(params.N)
+        for steps in (1, 3):
+            got = engine.blind_rotate_batch(t, steps)
+            assert np.array_equal(got, two.blind_rotate_batch(t, steps))
+            assert np.array_equal(got[7].reshape(-1), orc.blind_rotate(params, pl, keys.bk_f, None, t[7], steps))
+    finally:
+        two.close()
+
+
 @pytest.fixture(scope="module")
 def setup2048(orc):
     import rustfhe_amd as R
