@@ -10,7 +10,7 @@
 //   s0 = hand0; inverse transform (trade with (0, 1 - H)), += b-poly  R: s1 = hand1 + rows 3..5 of component 1; inverse, += a-poly
 //
 // A wave runs one parity of a 512-point transform: the 256-point sub-network of rtfhe_sub256.hpp (4 points per lane, its 15 twiddles per direction
-// resident in registers), then the size-2 stage across the parities as a HALF-WIDTH trade -- the even wave finishes both outputs of the butterflies
+// resident in registers, its exchanges as 8-byte planes: at two waves per SIMD they beat the 16-byte form the latency kernel uses, 4.05 -> 3.89 ms), then the size-2 stage across the parities as a HALF-WIDTH trade -- the even wave finishes both outputs of the butterflies
 // k = 4 v + m, m < 2, the odd wave m >= 2: it sends two complex values per lane and receives two -- so that both sides of a parity hold the same
 // spectrum points in the same registers (register j < 2: point 2k, register 2 + j: point 2k + 1, k = 4 v + 2 H + j; key layout: k_bk_to_p4) and
 // the partial sums travel lane to lane.  Buffers, flags, fold order, publishing of the accumulator words: as in k_bootstrap_eo4.
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
         // flag and the wait
 #ifdef PAIR4_ROWS_IN_TURN     // A/B: one row's three passes after the other's
 #pragma unroll
-        for (int jj = 0; jj < L; jj++) sub256_forward_a(yr[jj], yi[jj], qf, wbuf, ln);
+        for (int jj = 0; jj < L; jj++) sub256_forward_a<Q4Regs, Q4NoHook, true>(yr[jj], yi[jj], qf, wbuf, ln);
 #else
-        sub256_forward_a_multi<L>(yr, yi, qf, wbuf, ln);
+        sub256_forward_a_multi<L, true>(yr, yi, qf, wbuf, ln);
 #endif
         if constexpr (PAIR4_PRIO == 5 && GATES == 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
         sub256_forward_b<ODD, BOOT_TRIV>(yr[0], yi[0], qf);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
             inv_cross_write(parity, sre, sim, wbuf, lane); P4_ARRIVE();
             P4_WAIT(); inv_cross_read(parity, sre, sim, rbuf, lane);
             widx ^= 1;
-            sub256_inverse<ODD, BOOT_TRIV>(sre, sim, qi, xb(SIDE, widx), lane);
+            sub256_inverse<ODD, BOOT_TRIV, true>(sre, sim, qi, xb(SIDE, widx), lane);
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 const int c = 2 * (lane + 64 * m) + H;

@@ -68,13 +68,31 @@ struct Q4 {
     __host__ __device__ static constexpr int stride() {
         return X == 1 ? (LAYOUT == 1 ? 80 : 16) : X == 2 ? (LAYOUT == 2 ? 20 : 4) : (LAYOUT == 3 ? 5 : 1);
     }
-    // one 16-byte LDS access per complex value
-    template <int FROM, int TO>
+    // PLANES = false: one 16-byte LDS access per complex value (what the latency kernel wants: its waves wait on their own LDS round trips, and half
+    // the instructions are worth 2 %); true: the real and the imaginary parts as 8-byte accesses to two planes of XS doubles in the same buffer (what
+    // k_bootstrap_pair4 wants at two waves per SIMD: 4.05 -> 3.89 ms per 512 gates).  profiles/r04/pair4_ab.log
+    template <int FROM, int TO, bool PLANES = false>
     __device__ __forceinline__ static void exchange(double (&re)[R], double (&im)[R], cplx* __restrict__ xc, int lane) {
         constexpr int X = FROM < TO ? FROM : TO;
         static_assert(FROM + TO == 2 * X + 1, "neighbouring layouts");
         const int bw = base<X, FROM>(lane), br = base<X, TO>(lane);
         constexpr int sw = stride<X, FROM>(), sr = stride<X, TO>();
+      if constexpr (PLANES) {
+        double* xre = reinterpret_cast<double*>(xc);
+        double* xim = xre + XS;
+#pragma unroll
+        for (int m = 0; m < R; m++) lds_st(&xre[bw + sw * m], re[m]);
+#pragma unroll
+        for (int m = 0; m < R; m++) lds_st(&xim[bw + sw * m], im[m]);
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < R / 2; m++) {
+            re[m] = lds_ld(&xre[br + sr * m]); re[m + 2] = lds_ld(&xre[br + sr * (m + 2)]);
+            im[m] = lds_ld(&xim[br + sr * m]); im[m + 2] = lds_ld(&xim[br + sr * (m + 2)]);
+        }
+        wave_lds_sync();
+        return;
+      }
 #pragma unroll
         for (int m = 0; m < R; m++) lds_st128(&xc[bw + sw * m], re[m], im[m]);
         wave_lds_sync();
@@ -92,37 +110,37 @@ struct Q4 {
 struct Q4NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // part A: twist and the three passes that need the exchange buffer; part B: the last pass, registers only (a caller with several rows and one
 // buffer runs A for all of them first)
-template <typename W, typename HOOK = Q4NoHook>
+template <typename W, typename HOOK = Q4NoHook, bool PLANES = false>
 __device__ __forceinline__ void sub256_forward_a(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane, HOOK after_exchange = HOOK()) {
     cplx wt[4], w1[3], w2[3], w3[3];
     w.get_wt(wt); w.get_w1(w1);
     twist_mul<4>(re, im, wt);
     P12<4, 1>::fwd(re, im, w1);
     w.get_w2(w2);
-    Q4::exchange<1, 2>(re, im, xc, lane);
+    Q4::exchange<1, 2, PLANES>(re, im, xc, lane);
     after_exchange(1);
     P12<4, 1>::fwd(re, im, w2);
     w.get_w3(w3);
-    Q4::exchange<2, 3>(re, im, xc, lane);
+    Q4::exchange<2, 3, PLANES>(re, im, xc, lane);
     after_exchange(2);
     P12<4, 1>::fwd(re, im, w3);
-    Q4::exchange<3, 4>(re, im, xc, lane);
+    Q4::exchange<3, 4, PLANES>(re, im, xc, lane);
     after_exchange(3);
 }
 // ... for NR rows side by side, pass by pass: a row's exchange is in flight while the other rows compute (DS instructions of a wave execute in
 // order, so the rows share the buffer back to back), and every pass loads nothing (the twiddles are the caller's registers)
-template <int NR, typename W>
+template <int NR, bool PLANES, typename W>
 __device__ __forceinline__ void sub256_forward_a_multi(double (&re)[NR][4], double (&im)[NR][4], const W& w, cplx* __restrict__ xc, int lane) {
     cplx wt[4], w1[3], w2[3], w3[3];
     w.get_wt(wt); w.get_w1(w1);
 #pragma unroll
-    for (int j = 0; j < NR; j++) { twist_mul<4>(re[j], im[j], wt); P12<4, 1>::fwd(re[j], im[j], w1); Q4::exchange<1, 2>(re[j], im[j], xc, lane); }
+    for (int j = 0; j < NR; j++) { twist_mul<4>(re[j], im[j], wt); P12<4, 1>::fwd(re[j], im[j], w1); Q4::exchange<1, 2, PLANES>(re[j], im[j], xc, lane); }
     w.get_w2(w2);
 #pragma unroll
-    for (int j = 0; j < NR; j++) { P12<4, 1>::fwd(re[j], im[j], w2); Q4::exchange<2, 3>(re[j], im[j], xc, lane); }
+    for (int j = 0; j < NR; j++) { P12<4, 1>::fwd(re[j], im[j], w2); Q4::exchange<2, 3, PLANES>(re[j], im[j], xc, lane); }
     w.get_w3(w3);
 #pragma unroll
-    for (int j = 0; j < NR; j++) { P12<4, 1>::fwd(re[j], im[j], w3); Q4::exchange<3, 4>(re[j], im[j], xc, lane); }
+    for (int j = 0; j < NR; j++) { P12<4, 1>::fwd(re[j], im[j], w3); Q4::exchange<3, 4, PLANES>(re[j], im[j], xc, lane); }
 }
 template <bool ODD, bool TRIV, typename W>
 __device__ __forceinline__ void sub256_forward_b(double (&re)[4], double (&im)[4], const W& w) {
@@ -146,7 +164,7 @@ __device__ __forceinline__ void sub256_forward(double (&re)[4], double (&im)[4],
 
 // Inverse: in = in_H[j] in layout L4 (the size-2 stage across the parities already applied: in_0[j] = s[2j] + s[2j + 1], in_1[j] = s[2j] + (-s[2j + 1]));
 // out = this parity's coefficients, untwisted (the 2/N of fft_processor_spqlios.cpp:158 is in the table), layout L1.
-template <bool ODD, bool TRIV, typename W>
+template <bool ODD, bool TRIV, bool PLANES = false, typename W>
 __device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4], const W& w, cplx* __restrict__ xc, int lane) {
     cplx wt[4], w1[3], w2[3], w3[3], w4[2];
     w.get_w4(w4); w.get_w3(w3);
@@ -159,13 +177,13 @@ __device__ __forceinline__ void sub256_inverse(double (&re)[4], double (&im)[4],
         else      { re[m] = ra + jb; re[m + 1] = ra + (-jb); im[m] = ja + (-rb); im[m + 1] = ja + rb; }
     }
     inv_stage_tw<4, 1, false, TRIV && !ODD>(re, im, w4);
-    Q4::exchange<4, 3>(re, im, xc, lane);
+    Q4::exchange<4, 3, PLANES>(re, im, xc, lane);
     P12<4, 1>::inv(re, im, w3);
     w.get_w2(w2);
-    Q4::exchange<3, 2>(re, im, xc, lane);
+    Q4::exchange<3, 2, PLANES>(re, im, xc, lane);
     P12<4, 1>::inv(re, im, w2);
     w.get_w1(w1); w.get_wt(wt);
-    Q4::exchange<2, 1>(re, im, xc, lane);
+    Q4::exchange<2, 1, PLANES>(re, im, xc, lane);
     P12<4, 1>::inv(re, im, w1);
     twist_mul<4>(re, im, wt);
 }
