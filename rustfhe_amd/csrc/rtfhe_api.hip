@@ -296,7 +296,8 @@ struct rtfhe_ctx {
     cplx* d_etw = nullptr;            // N = 2048: tables of k_bootstrap_eo
     cplx* d_ebk = nullptr;            // N = 2048: key spectra in the even / odd layout
     cplx* d_p4bk = nullptr;           // N = 1024: key spectra in the layout of k_bootstrap_pair4
-    int pair4 = 1;                    // N = 1024, batches and tails of more than wg_max and up to two gates per CU: 1 = four waves per gate (RTFHE_PAIR4)
+    int pair4 = 3;                    // N = 1024, four waves per gate (k_bootstrap_pair4) for batches and tails of more than wg_max gates and up to
+                                      // `pair4` gates per CU (RTFHE_PAIR4: 0 = never, 2, 3 = default, 4 = A/B: full rounds too, 9 = A/B: also instead of the latency kernel)
     unsigned long long tune = 0;      // tuning builds only (rtfhe_debug_set_tune): handed to the kernels as BootstrapArgs::tune
     int eo4 = 1;                      // N = 2048, up to two gates per CU: 1 = four waves per gate (k_bootstrap_eo4), 0 = two (RTFHE_N2048_EO4)
     int n2048_kernel = -1;            // -1 = by launch shape (below), 0 = parity split (k_bootstrap_eo), 1 = top-bit split (k_bootstrap_halves);
@@ -615,19 +616,26 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         const size_t out_words = mode_out_words(a, 1 << LOGN);
         const size_t round = (size_t)4 * ctx->num_cus, count = (size_t)a.count;
         const size_t full = count / round * round, rem = count - full;
-        if (full)
-            if (int rc = launch_bootstrap_pair10(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
+        if (full) {
+            const BootstrapArgs seg = batch_segment(ctx, a, 0, full, out_words);
+            if (ctx->pair4 >= 4 && ctx->pair4 != 9 && ctx->d_p4bk && (seg.mode == MODE_EXTRACT || seg.mode == MODE_BLIND_ROTATE)) { if (int rc = launch_bootstrap_pair4_g<4>(ctx, seg, s)) return rc; }      // A/B: RTFHE_PAIR4=4
+            else if (int rc = launch_bootstrap_pair10(ctx, seg, s)) return rc;
+        }
         if (rem) {
             const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
             if (rem <= (size_t)ctx->wg_max) {
-                if (ctx->pair4 == 2 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<1>(ctx, tail, s);     // A/B: RTFHE_PAIR4=2
+                if (ctx->pair4 == 9 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<1>(ctx, tail, s);     // A/B: RTFHE_PAIR4=9
                 return launch_bootstrap_wg10(ctx, tail, s);
             }
             if (rem <= (size_t)2 * ctx->num_cus) {
-                if (ctx->pair4 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<2>(ctx, tail, s);
+                if (ctx->pair4 >= 2 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<2>(ctx, tail, s);
                 return launch_bootstrap_pair10_g<2>(ctx, tail, s);
             }
-            if (rem <= (size_t)3 * ctx->num_cus) return launch_bootstrap_pair10_g<3>(ctx, tail, s);
+            if (rem <= (size_t)3 * ctx->num_cus) {
+                if (ctx->pair4 >= 3 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<3>(ctx, tail, s);
+                return launch_bootstrap_pair10_g<3>(ctx, tail, s);
+            }
+            if (ctx->pair4 >= 4 && ctx->pair4 != 9 && ctx->d_p4bk && (tail.mode == MODE_EXTRACT || tail.mode == MODE_BLIND_ROTATE)) return launch_bootstrap_pair4_g<4>(ctx, tail, s);     // A/B: RTFHE_PAIR4=4
             return launch_bootstrap_pair10(ctx, tail, s);
         }
         return 0;
@@ -1024,6 +1032,7 @@ int prime_kernel_attributes(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 3>, PairLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 2>, PairLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_wg<10, 3, 6, 8, 2, KSQ>, WgLds<10, 3>::bytes(npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 3>, Pair4Lds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 2>, Pair4Lds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 1>, Pair4Lds::bytes(1, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<10>(4, npad, bootstrap_dual_xbuf(10, 4)))) return rc;

@@ -1,5 +1,7 @@
 // rtfhe_kernels_pair4.hpp -- N = 1024 with FOUR waves per gate: (polynomial, parity of the point index).  k_bootstrap_eo4 (rtfhe_kernels_eo4.hpp)
-// one size down, for batches and tails of up to two gates per CU, where k_bootstrap_pair leaves every SIMD one wave to issue from.
+// one size down, for batches and tails of more than one and up to three gates per CU, where k_bootstrap_pair leaves SIMDs one wave to issue from.
+// (Three gates per workgroup: 168 registers per wave, the parity tables read pass by pass from LDS; four -- 128 registers, 22 spilled -- lose
+// 12 % against k_bootstrap_pair's full round.)
 //
 //   wave (side 0, parity H), owns the b-poly's points of parity H     wave (side 1, parity H), owns the a-poly's points of parity H
 //   gather / decompose, rows 0..2 forward, trades with (0, 1 - H)     gather / decompose, rows 3..5 forward, trades with (1, 1 - H)
@@ -27,6 +29,7 @@
 #ifndef PAIR4_PRIO
 #define PAIR4_PRIO 4
 #endif
+// (at three gates per workgroup, where the two sides of a parity do not always share a SIMD, the same schedule: 5.83 vs 6.04 ms per 768 gates without)
 
 namespace rtfhe {
 
@@ -40,7 +43,9 @@ struct Pair4Lds {
     static constexpr size_t FLAGS = 32;                                // per gate: 4 trade counters + 4 hand-off counters
     __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }
     __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 1024 * 4 + abar_bytes(npad) + 4 * XB + FLAGS; }
-    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return (size_t)gates * gate_bytes(npad); }
+    // three gates per workgroup (168 registers per wave): the parity tables are staged into LDS in front of the gates
+    __host__ __device__ static constexpr size_t tw_bytes(int gates) { return gates >= 3 ? (size_t)Q4Tw::TOTAL * sizeof(cplx) : 0; }
+    __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return tw_bytes(gates) + (size_t)gates * gate_bytes(npad); }
 };
 
 // key spectra: device layout of the N = 1024 kernels ([n][row][comp][8][64]: lane v, register q <-> point (v << 3) | q) -> the layout the waves of
@@ -75,7 +80,12 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
     const GateIo io = gate_io(a, g);
     const bool live = g_raw < a.count && io.ok;
 
-    unsigned char* gbase = smem + (size_t)slot * Pair4Lds::gate_bytes(a.npad);
+    constexpr bool TWLDS = GATES >= 3;
+    if constexpr (TWLDS) {
+        cplx* qt = reinterpret_cast<cplx*>(smem);
+        for (int idx = tid; idx < Q4Tw::TOTAL; idx += 256 * GATES) qt[idx] = a.tw[G::TW_TOTAL + idx];
+    }
+    unsigned char* gbase = smem + Pair4Lds::tw_bytes(GATES) + (size_t)slot * Pair4Lds::gate_bytes(a.npad);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
     uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
     cplx* xbase = reinterpret_cast<cplx*>(gbase + (size_t)2 * N * 4 + Pair4Lds::abar_bytes(a.npad));
@@ -110,9 +120,15 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
     __syncthreads();
 
     // this parity's twiddles, both directions: resident over the whole blind rotation (the parity tables ride behind the staged table)
-    Q4Regs qf, qi;
-    qf.load(a.tw + G::TW_TOTAL + Q4Tw::off(0, H), lane0);
-    qi.load(a.tw + G::TW_TOTAL + Q4Tw::off(1, H), lane0);
+    typedef typename std::conditional<TWLDS, Q4Lds, Q4Regs>::type QT;
+    QT qf, qi;
+    if constexpr (TWLDS) {
+        qf = Q4Lds{reinterpret_cast<const cplx*>(smem) + Q4Tw::off(0, H), lane0};
+        qi = Q4Lds{reinterpret_cast<const cplx*>(smem) + Q4Tw::off(1, H), lane0};
+    } else {
+        qf.load(a.tw + G::TW_TOTAL + Q4Tw::off(0, H), lane0);
+        qi.load(a.tw + G::TW_TOTAL + Q4Tw::off(1, H), lane0);
+    }
 
     // key rows rc = 2 row + comp of the step, this wave's half of the points (k_bk_to_p4); two buffers, refilled as a multiply-accumulate retires
     const size_t trgsw_cplx = (size_t)2 * L * 2 * 2 * R * 64;
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        if constexpr (PAIR4_PRIO != 0 && GATES == 2) __builtin_amdgcn_s_setprio(SIDE == 0 ? 2 : 1);
+        if constexpr (PAIR4_PRIO != 0 && GATES >= 2) __builtin_amdgcn_s_setprio(SIDE == 0 ? 2 : 1);
         cplx* wbuf = xb(SIDE, widx);              // the buffer I own (write next)
         cplx* rbuf = xb(SIDE, widx ^ 1);          // my parity partner's (read after its arrival)
         int ln = lane0;
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
         // flag and the wait
 #ifdef PAIR4_ROWS_IN_TURN     // A/B: one row's three passes after the other's
 #pragma unroll
-        for (int jj = 0; jj < L; jj++) sub256_forward_a<Q4Regs, Q4NoHook, true>(yr[jj], yi[jj], qf, wbuf, ln);
+        for (int jj = 0; jj < L; jj++) sub256_forward_a<QT, Q4NoHook, true>(yr[jj], yi[jj], qf, wbuf, ln);
 #else
         sub256_forward_a_multi<L, true>(yr, yi, qf, wbuf, ln);
 #endif
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
         sub256_forward_b<ODD, BOOT_TRIV>(yr[2], yi[2], qf);
         P4_WAIT(); cross_read(parity, yr[1], yi[1], wbuf, ln);
         cross_write(parity, yr[2], yi[2], wbuf, ln); P4_ARRIVE();
-        if constexpr (PAIR4_PRIO == 4 && GATES == 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PAIR4_PRIO == 4 && GATES >= 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
         fetch(bB, i, rc0 + 2);                      // (second row, component 0)
         P4_WAIT(); cross_read(parity, yr[2], yi[2], rbuf, ln);
         widx ^= 1;                                  // three trades: I now own the buffer I read last

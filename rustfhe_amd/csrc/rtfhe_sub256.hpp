@@ -52,6 +52,30 @@ struct Q4Regs {
     __device__ __forceinline__ void get_w3(cplx (&o)[3]) const { for (int e = 0; e < 3; e++) o[e] = w3[e]; }
     __device__ __forceinline__ void get_w4(cplx (&o)[2]) const { o[0] = w4[0]; o[1] = w4[1]; }
 };
+// ... or read pass by pass from a copy of the table in LDS (k_bootstrap_pair4 at three gates per workgroup: 168 registers per wave leave no room
+// for 30 resident complex values); a pass's loads are issued before the exchange in front of it
+struct Q4Lds {
+    const cplx* t;       // LDS: Q4Tw::ONE entries of this wave's direction and parity
+    int lane;
+    __device__ __forceinline__ void get_wt(cplx (&o)[4]) const {
+#pragma unroll
+        for (int m = 0; m < 4; m++) o[m] = t[Q4Tw::TW + m * 64 + lane];
+    }
+    __device__ __forceinline__ void get_w1(cplx (&o)[3]) const {
+#pragma unroll
+        for (int e = 0; e < 3; e++) o[e] = t[Q4Tw::P1 + e * 64 + lane];
+    }
+    __device__ __forceinline__ void get_w2(cplx (&o)[3]) const {
+#pragma unroll
+        for (int e = 0; e < 3; e++) o[e] = t[Q4Tw::P2 + e * 16 + (lane & 15)];
+    }
+    __device__ __forceinline__ void get_w3(cplx (&o)[3]) const {
+#pragma unroll
+        for (int e = 0; e < 3; e++) o[e] = t[Q4Tw::P3 + e * 4 + (lane & 3)];
+    }
+    __device__ __forceinline__ void get_w4(cplx (&o)[2]) const { o[0] = t[Q4Tw::P4]; o[1] = t[Q4Tw::P4 + 1]; }
+};
+
 struct Q4 {
     static constexpr int R = 4;
     static constexpr int XS = 320;               // complex slots of an exchange buffer (the largest padded slot is 318); 16-byte aligned

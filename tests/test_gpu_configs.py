@@ -75,8 +75,8 @@ def test_config3_whole_batch_65536_on_one_gpu(engine, orc, params, keys):
 
 
 def test_four_waves_per_gate_agree_with_two_at_n1024(engine, orc, params, keys, monkeypatch):
-    """N = 1024, batches and tails of more than 256 and up to 512 gates: the default dispatch gives a gate four waves -- (polynomial, parity of the
-    point index), k_bootstrap_pair4 -- where RTFHE_PAIR4=0 keeps k_bootstrap_pair's two: the same arithmetic, so identical words for whole gates,
+    """N = 1024, batches and tails of more than 256 and up to 768 gates (two or three gates per CU): the default dispatch gives a gate four waves --
+    (polynomial, parity of the point index), k_bootstrap_pair4 -- where RTFHE_PAIR4=0 keeps k_bootstrap_pair's two: the same arithmetic, so identical words for whole gates,
     for a tail behind a full round, and for blind-rotation prefixes (the latter also against the oracle)."""
     import rustfhe_amd as R
     rng = np.random.default_rng(44)
@@ -90,7 +90,7 @@ def test_four_waves_per_gate_agree_with_two_at_n1024(engine, orc, params, keys, 
         two.load_bk_torus(keys.bk_t)
         two.load_ksk(keys.ksk)
         ref = two.gate_batch(R.NAND, c0, c1)
-        for k in (257, 300, 511, 512, G):
+        for k in (257, 300, 511, 512, 513, 700, 768, G):
             out = engine.gate_batch(R.NAND, c0[:k], c1[:k])
             assert np.array_equal(out, ref[:k]), k
         assert keys.decrypt_bits(engine.gate_batch(R.XOR, c0[:400], c1[:400])) == list(b0[:400] ^ b1[:400])
