@@ -40,14 +40,14 @@ CUS, SIMDS_PER_CU, DP_LANES_PER_CLK, CLOCK_HZ = 256, 4, 16, 2.4e9
 FP64_VALU_PEAK = CUS * SIMDS_PER_CU * DP_LANES_PER_CLK * CLOCK_HZ     # 39.32e12 lane-ops/s: one v_add/v_mul_f64 lane result each
 
 
-def dp_wave_instr_per_cmux(N=1024, l=3, split="parity"):
+def dp_wave_instr_per_cmux(N=1024, l=3):
     """FP64-rate VALU wave-instructions one CMUX step costs, derived from the transform structure of
     rustfhe_amd/csrc/rtfhe_device.hpp (checked against the built kernel's ISA by tests/test_bench_launcher.py):
     the mirror arithmetic may not fuse, so every product and every sum is one v_mul_f64 / v_add_f64.
     `reference` is the reference's operation list; the kernels execute `total` = reference minus the instructions that cannot change a
     torus word: the 6 multiplies / sums of the one butterfly per transform whose twiddle is exactly (1, 0) (N = 1024: the halfnn = 4
-    stage of every 512-point transform; N = 2048, top-bit split (k_bootstrap_halves, split="top_bit"): of both 512-point halves; parity
-    split (k_bootstrap_eo, the default kernel): three in the even-point network -- one in its halfnn = 8 stage, two in halfnn = 4) and, in
+    stage of every 512-point transform; N = 2048 (k_bootstrap_eo, transforms split over two waves by the parity of the point index):
+    three in the even-point network -- one in its halfnn = 8 stage, two in halfnn = 4) and, in
     the two-waves-per-gate kernel at N = 1024, the "+0.0 +" of the first row of component 0's fold."""
     P = N // 2
     R = P // 64                               # points per lane
@@ -63,7 +63,7 @@ def dp_wave_instr_per_cmux(N=1024, l=3, split="parity"):
     arith = 2 * l * transform + 2 * transform + 2 * 2 * l * mac + 2 * trunc_add
     cvt = 2 * l * 2 * R + 2 * 2 * R           # v_cvt_f64_i32 per digit, v_trunc_f64 per output word
     transforms = 2 * l + 2
-    unit_per_transform = 6 * (1 if N == 1024 else 3 if split == "parity" else 2)      # per unit-twiddle butterfly: 4 products + 2 sums
+    unit_per_transform = 6 * (1 if N == 1024 else 3)      # per unit-twiddle butterfly: 4 products + 2 sums
     unit = unit_per_transform * transforms
     first_row = 2 * R if N == 1024 else 0                         # slot P of side 0 only
     return {"add_mul": arith - unit - first_row, "cvt_trunc": cvt, "total": arith - unit - first_row + cvt, "reference": arith + cvt,
@@ -529,10 +529,9 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
             xo = torch.empty_like(x0)
             ms, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xo, G, stream), 5)
             ok5 = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
-            top_bit = os.environ.get("RTFHE_N2048_KERNEL") == "halves"          # the library's default is the parity split at every shape
-            ops5 = dp_wave_instr_per_cmux(2048, p5.l, "top_bit" if top_bit else "parity")["total"]
+            ops5 = dp_wave_instr_per_cmux(2048, p5.l)["total"]
             sec["config5_n2048_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3),
-                                               "kernel": "k_bootstrap_halves" if top_bit else "k_bootstrap_eo",
+                                               "kernel": "k_bootstrap_eo",
                                                "dp_wave_instr_per_cmux": ops5, "roofline_frac_fp64": fp64_frac(ops5, p5.n, G, ms * 1e-3), "ok": ok5}
             # below a full round (the library's default: four waves per gate, k_bootstrap_eo4, at up to two gates per CU): 3 launches each
             small = {}

@@ -40,6 +40,7 @@ extern "C" {
     pub fn rtfhe_ctx_create(p: *const rtfhe_params, device_id: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
     pub fn rtfhe_ctx_create_multi(p: *const rtfhe_params, device_ids: *const c_int, n_dev: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
     pub fn rtfhe_ctx_device_count(ctx: *const rtfhe_ctx) -> c_int;
+    pub fn rtfhe_ctx_memory_bytes(ctx: *const rtfhe_ctx, d: c_int, bytes: *mut usize) -> c_int;
     pub fn rtfhe_shard_range(count: usize, d: c_int, n_dev: c_int, begin: *mut usize, end: *mut usize) -> c_int;
     pub fn rtfhe_host_alloc(bytes: usize) -> *mut c_void;
     pub fn rtfhe_host_free(p: *mut c_void);
@@ -70,6 +71,9 @@ extern "C" {
 
     pub fn rtfhe_gate_batch_dev(ctx: *mut rtfhe_ctx, op: c_int, d_in0: *const c_void, d_in1: *const c_void, d_out: *mut c_void,
                                 count: usize, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_mux_batch_dev(ctx: *mut rtfhe_ctx, d_c: *const c_void, d_in0: *const c_void, d_in1: *const c_void, d_out: *mut c_void,
+                               count: usize, stream: *mut c_void) -> c_int;
+    pub fn rtfhe_bootstrap_batch_dev(ctx: *mut rtfhe_ctx, d_tlwe: *const c_void, d_out: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
     pub fn rtfhe_circuit_wave_dev(ctx: *mut rtfhe_ctx, d_ops: *const c_void, d_idx0: *const c_void, d_idx1: *const c_void,
                                   d_idx_out: *const c_void, d_wires: *mut c_void, num_wires: usize, count: usize, stream: *mut c_void) -> c_int;
     pub fn rtfhe_circuit_create(ctx: *mut rtfhe_ctx, d_ops: *const c_void, d_idx0: *const c_void, d_idx1: *const c_void, d_idx_out: *const c_void,

@@ -17,10 +17,10 @@
  *   rtfhe_load_ksk                   <- the same key without the entry t = 4 of every level, which identity_key_switch never reads
  *                                       (its digits are basebit = 2 bits wide, tlwe.rs:43-73): [[TLWERep; 3]; 8]
  *   rtfhe_gate_batch[_dev]           <- TFHE::hom_nand/and/or/xor/not (hom_nand/src/tfhe.rs:41-71), count gates at once
- *   rtfhe_mux_batch                  <- TFHE::hom_mux (tfhe.rs:27-40)
+ *   rtfhe_mux_batch[_dev]            <- TFHE::hom_mux (tfhe.rs:27-40)
  *   rtfhe_circuit_wave_dev           <- eval_logic_expr over impl Logip for TFHE (nander/src/lib.rs:40-89), one level at a time
  *   rtfhe_circuit_create / _launch   <- the same evaluation, all levels of a netlist recorded once and replayed as one submission
- *   rtfhe_bootstrap_batch            <- TFHE::bootstrap (tfhe.rs:73-80)
+ *   rtfhe_bootstrap_batch[_dev]      <- TFHE::bootstrap (tfhe.rs:73-80)
  *   rtfhe_blind_rotate_batch         <- TFHE::blind_rotate with the gate test vector (tfhe.rs:81-113)
  *   rtfhe_external_product_batch     <- Cross for TRGSWRepF (hom_nand/src/trgsw.rs:264-306)
  *   rtfhe_key_switch_batch           <- TLWERep::identity_key_switch (hom_nand/src/tlwe.rs:43-73)
@@ -101,12 +101,21 @@ void rtfhe_default_params(rtfhe_params *p);
 int rtfhe_ctx_create(const rtfhe_params *p, int device_id, rtfhe_ctx **out);
 /* One context over n_dev GPUs of the node (what a Rust `hom_nand_batch` binds for a whole-node batch).
  * device_ids[0] is the primary.  Keys loaded into the context are transformed once on the primary and copied
- * device-to-device to the others.  The host-pointer batch calls (rtfhe_gate_batch, rtfhe_mux_batch, rtfhe_bootstrap_batch)
- * shard contiguous gate ranges over the devices -- device d gets [count d / n_dev, count (d+1) / n_dev) -- with one host
- * thread and one stream per device and direct host<->device copies per device; outputs land at the same indices as on one
- * device and are bit-identical.  *_dev and stage-level calls run on the primary device only. */
+ * device-to-device to the others.  Every batch call shards contiguous gate ranges over the devices -- device d gets
+ * [count d / n_dev, count (d+1) / n_dev) -- and outputs land at the same indices as on one device, bit-identical:
+ *   - host-pointer calls (rtfhe_gate_batch, rtfhe_mux_batch, rtfhe_bootstrap_batch, rtfhe_blind_rotate_batch): one host thread and one
+ *     stream per device, direct host<->device copies per device;
+ *   - device-pointer calls (rtfhe_gate_batch_dev, rtfhe_mux_batch_dev, rtfhe_bootstrap_batch_dev): the batch lives on the PRIMARY device;
+ *     every other device pulls its range over xGMI (hipMemcpyPeerAsync on its own stream), bootstraps it and pushes the outputs back,
+ *     while the primary computes its own range; the caller's stream then waits for the other devices' events, so stream order holds as
+ *     on one device and the call stays asynchronous.  Inside a stream capture the whole batch stays on the primary.
+ * Netlist waves / circuits and stage-level calls run on the primary device only.  A device may be named more than once: every entry is
+ * a full context of its own (stream, staging buffers, key replica). */
 int rtfhe_ctx_create_multi(const rtfhe_params *p, const int *device_ids, int n_dev, rtfhe_ctx **out);
 int rtfhe_ctx_device_count(const rtfhe_ctx *ctx);      /* devices behind this context (1 for rtfhe_ctx_create) */
+/* device memory entry d (0 = primary) of the context holds right now, in bytes: the keys in every layout built so far (second layouts of
+ * the bootstrapping key are built by the first batch whose kernel shape reads them), tables, staging and scratch buffers */
+int rtfhe_ctx_memory_bytes(const rtfhe_ctx *ctx, int d, size_t *bytes);
 /* the range [*begin, *end) of a `count`-gate host batch that entry d of an n_dev-device context bootstraps (no GPU needed) */
 int rtfhe_shard_range(size_t count, int d, int n_dev, size_t *begin, size_t *end);
 void rtfhe_ctx_destroy(rtfhe_ctx *ctx);
@@ -156,6 +165,9 @@ int rtfhe_bootstrap_batch(rtfhe_ctx *ctx, const uint32_t *tlwe, uint32_t *out, s
 /* ---- the hot path: device buffers, asynchronous on `stream` (a hipStream_t, may be NULL) ---- */
 int rtfhe_gate_batch_dev(rtfhe_ctx *ctx, int op, const void *d_in0, const void *d_in1, void *d_out,
                          size_t count, void *stream);
+int rtfhe_mux_batch_dev(rtfhe_ctx *ctx, const void *d_c, const void *d_in0, const void *d_in1, void *d_out,
+                        size_t count, void *stream);          /* d_out may alias none of the inputs */
+int rtfhe_bootstrap_batch_dev(rtfhe_ctx *ctx, const void *d_tlwe, void *d_out, size_t count, void *stream);
 /* one dependency wave of a gate netlist (the build-side counterpart of nander's eager tree walk, nander/src/lib.rs:72-89):
  * gate g reads rows idx0[g] and idx1[g] of the wire table d_wires (u32[num_wires][n+1]), applies ops[g] and writes row
  * idx_out[g]; all four arrays are int32[count] in device memory.  Gates of one call must be independent.  Indices and

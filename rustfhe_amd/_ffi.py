@@ -39,6 +39,7 @@ _SIGNATURES = {
     "rtfhe_shard_range": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rtfhe_ctx_create_multi": (C.c_int, ["PP", C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "rtfhe_ctx_device_count": (C.c_int, [C.c_void_p]),
+    "rtfhe_ctx_memory_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "rtfhe_ctx_destroy": (None, [C.c_void_p]),
     "rtfhe_host_alloc": (C.c_void_p, [C.c_size_t]),
     "rtfhe_host_free": (None, [C.c_void_p]),
@@ -63,6 +64,8 @@ _SIGNATURES = {
     "rtfhe_mux_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtfhe_gate_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rtfhe_mux_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rtfhe_bootstrap_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rtfhe_circuit_wave_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "rtfhe_circuit_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -127,6 +130,18 @@ def load(build_if_missing=True):
         import torch  # noqa: F401
     except Exception:
         pass
+    override = os.environ.get("RTFHE_LIB")          # a prebuilt library to load as it is (A/B runs: no staleness check, no rebuild)
+    if override:
+        path = os.path.abspath(override)
+        if not os.path.exists(path):
+            raise ImportError("RTFHE_LIB=%s does not exist" % override)
+        L = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = [C.POINTER(Params) if a == "PP" else a for a in args]
+        _lib = L
+        return L
     if build_if_missing:
         _build.build()
     if not os.path.exists(_build.LIB):

@@ -22,11 +22,8 @@ typedef double2 cplx;  // .x = re / cos, .y = im / sin
 
 // The bootstrap kernels (outputs = torus words) skip the multiplies of the one butterfly per transform whose twiddle is exactly (1, 0) and the
 // "+0.0 +" of a fold's first row -- see fwd_stage_tw (TRIV0) for why no torus word can change; the host refuses a twiddle table whose entry is
-// not exactly (1, +-0) (check_unit_twiddles, rtfhe_api.hip).  -DRTFHE_BOOT_TRIV=0: the reference's operation list as it stands (A/B builds).
-#ifndef RTFHE_BOOT_TRIV
-#define RTFHE_BOOT_TRIV 1
-#endif
-constexpr bool BOOT_TRIV = RTFHE_BOOT_TRIV != 0;
+// not exactly (1, +-0) (unit_twiddles_ok, rtfhe_twiddles.hip).
+constexpr bool BOOT_TRIV = true;
 
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
@@ -75,20 +72,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 8 cycles where two ds_read_b64 take 2 + 2 (ds_write2_b64: 13 against 6 + 6) -- MI355X_MICROARCH.md, LDS table; measured
 // here: one 16-double exchange at two waves per SIMD costs the CU 81 cycles unpaired against 101 paired
 // (scripts/ubench/lds_forms.hip, profiles/r03/lds_forms.log), the headline kernel 7.35 -> 7.12 ms per 1024 gates.  A relaxed
-// wavefront-scope atomic access lowers to exactly the plain instruction and is never paired.  -DRTFHE_LDS_PAIRED: A/B builds.
+// wavefront-scope atomic access lowers to exactly the plain instruction and is never paired.
 __device__ __forceinline__ void lds_st(double* p, double v) {
-#ifdef RTFHE_LDS_PAIRED
-    *p = v;
-#else
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#endif
 }
 __device__ __forceinline__ double lds_ld(const double* p) {
-#ifdef RTFHE_LDS_PAIRED
-    return *p;
-#else
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#endif
 }
 // ... and one complex value as ONE 16-byte access (ds_write_b128 / ds_read_b128: 13 / 4 LDS cycles against 6 + 6 / 2 + 2 for its two halves, i.e.
 // the same LDS time, in half the instructions -- scripts/ubench/issue_mix.hip: at two waves per SIMD an instruction of any kind costs the SIMD's
@@ -267,9 +256,6 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
                                          double* __restrict__ xbuf, int lane, double* __restrict__ ximbuf = nullptr) {
     typedef Geo<LOGN> G;
     constexpr int R = G::R;
-#ifdef ABL_NOXCHG   // timing ablation only (wrong results): no LDS exchange at all
-    return;
-#endif
     auto slot = [&](int layout, int m) {
         // the pad map is the one of the exchange (f1 for L1<->L2, f2 for L2<->L3), the position the one of the layout
         const int pos = layout == 1 ? G::pos1(lane, m) : layout == 2 ? G::pos2(lane, m) : G::pos3(lane, m);
@@ -304,20 +290,16 @@ __device__ __forceinline__ void exchange(double (&re)[Geo<LOGN>::R], double (&im
             wave_lds_sync();
             return;
         }
-#ifndef ABL_NOXW
 #pragma unroll
         for (int m = 0; m < R; m++) lds_st(&xbuf[bw + sw * m], re[m]);
 #pragma unroll
         for (int m = 0; m < R; m++) lds_st(&xim[bw + sw * m], im[m]);
-#endif
         wave_lds_sync();
-#ifndef ABL_NOXR
 #pragma unroll
         for (int m = 0; m < R / 2; m++) {
             re[m] = lds_ld(&xbuf[br + sr * m]); re[m + R / 2] = lds_ld(&xbuf[br + sr * (m + R / 2)]);
             im[m] = lds_ld(&xim[br + sr * m]);  im[m + R / 2] = lds_ld(&xim[br + sr * (m + R / 2)]);
         }
-#endif
         wave_lds_sync();
     } else if constexpr (DUAL) {
         double* xim = ximbuf ? ximbuf : xbuf + G::XSLOTS;   // second buffer: caller's, or right behind the first

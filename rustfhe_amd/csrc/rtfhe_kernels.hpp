@@ -43,7 +43,6 @@ struct BootstrapArgs {
     int32_t num_wires;       // netlist mode: rows in the wire table; indices and opcodes are checked against it on the device
     int32_t* fault;          // netlist mode: set to 1 when a gate was skipped for an out-of-range index / unknown opcode
     unsigned long long* dbg;   // diagnostic builds only (RTFHE_WG_STAMPS): per-phase cycle sums of workgroup 0
-    unsigned long long tune;   // tuning builds only (-DPAIR_PRIO_RUNTIME, scripts/tune_prio.py): a priority schedule to try, 3 bits per (side, point)
 };
 
 // gate pre-step on one TLWE word (a-part: isb = false, b-part: isb = true), hom_nand/src/tfhe.rs:27-71
@@ -175,11 +174,7 @@ __device__ __forceinline__ void cmux_step(uint32_t* __restrict__ accbuf, int r, 
 // then gathers t/2 rows per coefficient of which 15/16 are non-zero instead of t rows of which 3/4 are: 9.8 MB instead of
 // 15.6 MB per gate through the L2 (the key switch is L2-bandwidth bound: all gates of a launch reach it together), for a
 // 2.5x larger table (156 MB, still resident in the Infinity Cache next to the bootstrapping key).
-#ifndef RTFHE_KS_GROUP        // A/B builds: 1 = the reference's per-level rows (no pre-summing)
-#define RTFHE_KS_GROUP 2
-#endif
-constexpr int KS_GROUP = RTFHE_KS_GROUP;
-static_assert(KS_GROUP == 1 || KS_GROUP == 2, "single levels or pairs");
+constexpr int KS_GROUP = 2;
 __host__ __device__ constexpr int ks_dev_rows(int N, int t, int basebit) { return N * (t / KS_GROUP) * ((1 << (basebit * KS_GROUP)) - 1); }
 
 template <int LOGN, int KS_T, int KS_BB, int KSQ, int KS_UI = 2 * KS_GROUP>
@@ -235,10 +230,6 @@ __global__ __launch_bounds__(256) void k_ksk_combine(const KskCombineArgs a) {
     for (int r = blockIdx.x; r <= rows; r += gridDim.x) {
         uint32_t* dst = a.out + (size_t)r * a.ksw;
         if (r == rows) { for (int w = threadIdx.x; w < a.ksw; w += blockDim.x) dst[w] = 0u; continue; }
-        if constexpr (KS_GROUP == 1) {      // A/B builds: the reference's rows as they are
-            for (int w = threadIdx.x; w < a.ksw; w += blockDim.x) dst[w] = a.raw[(size_t)r * a.ksw + w];
-            continue;
-        }
         const int c = r % PBASE1 + 1, ip = r / PBASE1, p = ip % PT, i = ip / PT;
         const int d0 = c >> KS_BB, d1 = c & BASE1;
         const int s0 = d0 ? ((i * KS_T + 2 * p) * BASE1 + d0 - 1) : zero_src;
@@ -266,11 +257,7 @@ __device__ __forceinline__ void key_switch_wave(const uint32_t* __restrict__ apr
 }
 
 // one wave per SIMD (<= 4 waves per workgroup, N = 1024): separate real/imaginary exchange buffers (see exchange<>)
-#ifdef RTFHE_NO_DUAL   // A/B builds only
-__host__ __device__ constexpr bool bootstrap_dual_xbuf(int, int) { return false; }
-#else
 __host__ __device__ constexpr bool bootstrap_dual_xbuf(int logn, int waves) { return logn == 10 && waves <= 4; }
-#endif
 template <int LOGN>
 __host__ __device__ constexpr size_t bootstrap_wave_lds_bytes(int npad, bool dual = false) {
     return (size_t)Geo<LOGN>::XSLOTS * sizeof(double) * (dual ? 2 : 1) + (size_t)2 * Geo<LOGN>::N * 4 + (size_t)npad * 4;

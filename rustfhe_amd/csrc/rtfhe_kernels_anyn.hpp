@@ -10,7 +10,7 @@
 //   inverse = fft_model   spqlios-fft-impl.cpp:204-397 (asm `fft`, spqlios-fft-avx.s:79-280):
 //             input times 2/N (fft_processor_spqlios.cpp:158); size 2 :248-269; size 4 :289-310; stages halfnn = 4 ... N/4: t = x1 w, x0 +- t
 //             :315-363; untwist by (cos, sin)(-2 pi j / 2N) :374-396; Torus32(int64_t(x)) fft_processor_spqlios.cpp:182
-// Tables: the host's natural-order arrays (HostTw in rtfhe_api.hip: same values as new_ifft_table / new_fft_table), eight arrays of P = N/2
+// Tables: the host's natural-order arrays (HostTw in rtfhe_host.hpp / rtfhe_twiddles.hip: same values as new_ifft_table / new_fft_table), eight arrays of P = N/2
 // doubles: twist cos / sin, untwist cos / sin, forward stages cos / sin (stage halfnn at P - 2 halfnn), inverse stages cos / sin (at halfnn - 4).
 #pragma once
 

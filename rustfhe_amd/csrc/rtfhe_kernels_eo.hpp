@@ -1,59 +1,35 @@
-// rtfhe_kernels_eo.hpp -- N = 2048, two waves per transform, split by the PARITY of the point index (round 4).
+// rtfhe_kernels_eo.hpp -- N = 2048 (BASELINE config 5): two waves per transform, split by the PARITY of the point index.
 //
-// k_bootstrap_halves splits a 1024-point transform by its top index bit: the reference's first forward stage (halfnn = 512) then crosses the two
-// waves, and it is a TWIDDLED stage -- half B carries its 6 extra FP64 instructions per point, both halves stop three times per polynomial to
-// trade twisted inputs row by row with nothing to do meanwhile, and the same again at the end of the inverse (profiles/r03/n2048_phase_stamps.log:
-// the trade phases take 12 k of a 58.5 k-cycle step for ~1,000 of its 8,160 FP64 instructions, half B idles a quarter of the step).
-//
-// Here wave H owns the points of parity H: i = 2 j + H, j in [0, 512).  Every radix-2 stage of the reference network pairs i with i + halfnn
-// (forward, decimation in frequency, spqlios-fft-impl.cpp:526-572; inverse, decimation in time, :315-363), and for halfnn >= 2 both have the same
-// parity: NINE of the ten stages stay inside a wave -- twist, halfnn = 512 ... 4 (eight twiddled stages), and this parity's half of the size-4 stage
-// (:575-603 / :289-310) -- as a 512-point network in j of exactly the shape the N = 1024 kernels run (8 points per lane, three in-register passes of
-// three stages, two wave-private exchanges), with the twiddle of pair (i, i + halfnn) = entry (i mod halfnn) = 2 (j mod halfnn/2) + H of the
-// reference's stage table.  Only the size-2 stage (halfnn = 1: x0 + x1, x0 + (-x1), no twiddle, :606-634 / :248-269) crosses the waves: it is the LAST
-// stage of the forward transform and the FIRST of the inverse.  Consequences:
+// At N = 2048 a polynomial's transform has 1024 complex points: 16 per lane in one wavefront, which with three digit rows side by side does not
+// fit the register file (k_bootstrap<11>, one wave per gate, lives in 512 registers with ~790 AGPR shuffles per step at the lone-wave issue rate).
+// So the two waves of a gate share every transform.  Wave H owns the points of parity H: i = 2 j + H, j in [0, 512).  Every radix-2 stage of the
+// reference network pairs i with i + halfnn (forward, decimation in frequency, spqlios-fft-impl.cpp:526-572; inverse, decimation in time,
+// :315-363), and for halfnn >= 2 both have the same parity: NINE of the ten stages stay inside a wave -- twist, halfnn = 512 ... 4 (eight
+// twiddled stages), and this parity's half of the size-4 stage (:575-603 / :289-310) -- as a 512-point network in j of exactly the shape the
+// N = 1024 kernels run (8 points per lane, three in-register passes of three stages, two wave-private exchanges), with the twiddle of pair
+// (i, i + halfnn) = entry (i mod halfnn) = 2 (j mod halfnn/2) + H of the reference's stage table.  Only the size-2 stage (halfnn = 1: x0 + x1,
+// x0 + (-x1), no twiddle, :606-634 / :248-269) crosses the waves: it is the LAST stage of the forward transform and the FIRST of the inverse.
 //   * both waves execute the same instruction stream (wave 1's only differences: table pointers, and "partner + (-mine)" where wave 0 has
-//     "mine + partner") -- the work is balanced by construction, no priority schedule has anything to even out;
+//     "mine + partner") -- the work is balanced by construction;
 //   * the forward trade comes after a row's pass 3: the NEXT row's pass 3 (and, for the last row, the first multiply-accumulates) run between
-//     a row's arrival flag and the wait for the partner's -- no wave ever sits at a synchronisation with nothing to issue;
-//   * gather, decomposition and twist are wave-private: no first-stage trade at all.
-// Each wave owns the spectrum points of its parity for the multiply-accumulate over all six rows and both components: the fold order
-// (trgsw.rs:290-299) holds trivially, no partial sums travel.  Buffer ownership ping-pongs as in k_bootstrap_halves (round 4): one arrival / wait per
-// trade, 3 per polynomial + 1 per inverse = 8 per step.  Same arithmetic DAG as the reference, every product and sum rounded on its own
-// (-ffp-contract=off): bit-identical to k_bootstrap_halves and k_bootstrap<11> (tests/test_gpu_configs.py::test_config5_*).
+//     a row's arrival flag and the wait for the partner's -- no wave sits at a synchronisation with nothing to issue;
+//   * gather, decomposition and twist are wave-private: no first-stage trade at all;
+//   * the stage across the waves sits right next to the pointwise multiply-accumulate, whose layout is free: each wave finishes BOTH outputs of the
+//     butterflies of half of the indices k (it sends 4 of its 8 values per lane and receives 4: half-width trade), and the key is stored in that
+//     layout (k_bk_to_eo).
+// Each wave owns the spectrum points it finished for the multiply-accumulate over all six rows and both components: the fold order
+// (trgsw.rs:290-299) holds trivially, no partial sums travel.  Buffer OWNERSHIP ping-pongs between the two waves: after a trade each wave owns the
+// buffer it has just read -- its previous writer is done with it (its writes precede its arrival flag), its reader is this wave itself (DS
+// instructions of a wave execute in order) -- so there is no "buffer free" synchronisation: ONE arrival / wait per trade, 3 per polynomial + 1 per
+// inverse = 8 per step.  Same arithmetic DAG as the reference, every product and sum rounded on its own (-ffp-contract=off): bit-identical to
+// k_bootstrap<11> (tests/test_gpu_configs.py::test_config5_*).
 // LDS: the per-parity stage tables of passes 1-3 (16 KiB forward, 2 KiB inverse); twist / untwist / inverse pass-1 tables in global memory.
+// The kernel this one replaced (split by the TOP index bit, rounds 2-4) and every variant measured on the way are in profiles/HISTORY.md.
 #pragma once
 
 #include <type_traits>
 
-#include "rtfhe_kernels_halves.hpp"
-
-#ifndef EO_PRIO_B
-#define EO_PRIO_B 0
-#endif
-// the priority staircase (see EO_STEP in the kernel): -1 = by launch shape (default), 0 = off, 1 = the raise as its own statement, 5 = inside the wait
-#ifndef EO_STAIRS
-#define EO_STAIRS -1
-#endif
-// the stage across the two waves: 1 = each wave finishes BOTH outputs of the butterflies of half of the indices k (it sends 4 of its 8 values per
-// lane and receives 4), 0 = each wave finishes one output of every butterfly (sends 8, receives 8: the first form of this kernel, A/B builds)
-#ifndef EO_HALF_TRADE
-#define EO_HALF_TRADE 1
-#endif
-// the inverse transforms of the two components: 1 = a loop, 2 = two copies of the code, 0 = by launch shape (default; see COMP_COPIES in the kernel)
-#ifndef EO_COMP_COPIES
-#define EO_COMP_COPIES 0
-#endif
-#ifndef EO_DS_ADD
-#define EO_DS_ADD 1
-#endif
-// (The accumulator as two parity planes per polynomial in LDS -- coefficient c at word 1024 (c & 1) + (c >> 1), so that a wave's gather and update touch
-// consecutive words instead of every second one -- removes the gather's 2-way bank conflicts (0.33 G conflict cycles per 1024-gate launch) and
-// measured +-0 to +1.4 %: 15.27 -> 15.34 ms per 1024 gates, 13.20 -> 13.39 per 768; the compiler's address arithmetic for it is two integer
-// instructions per coefficient longer.  profiles/r04/n2048_accumulator_planes_ab.log.  Not kept.)
-// (With half-width trades a buffer holds two of them.  Rows 0 and 1 of a polynomial in ONE trade -- 6 arrive / wait pairs per step instead of 8 --
-// measured +-0: 14.85 -> 14.81 ms per 1024 gates, 13.02 -> 13.17 per 768, profiles/r04/n2048_merged_trades_ab.log; the two components' sums before
-// the inverse in one trade as well made the register allocator spill 340 registers at 3-4 gates per workgroup.  Not kept.)
+#include "rtfhe_kernels_pair.hpp"
 
 namespace rtfhe {
 
@@ -72,11 +48,12 @@ struct EoTw {
 };
 
 struct EoLds {
-    typedef Geo<10> G;
+    typedef Geo<10> G;   // geometry of a parity's 512-point sub-network
     static constexpr size_t TW = (size_t)EoTw::LDS_CPLX * sizeof(cplx);
-    static constexpr size_t XB = HalvesLds::XB;
-    static constexpr size_t FLAGS = 16;
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + HalvesLds::abar_bytes(npad) + 2 * XB + FLAGS; }
+    static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers: hold 512 cplx
+    static constexpr size_t FLAGS = 16;       // two arrival counters per gate
+    __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }      // rotation amounts as u16
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB + FLAGS; }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
@@ -89,18 +66,14 @@ struct EoArgs {
 // key spectra: device layout of k_bootstrap<11> ([n][row][comp][16][64]: lane v, register q <-> point (v << 4) | q) -> the layout the waves of
 // k_bootstrap_eo hold their spectra in after the stage across them.  A parity's sub-network leaves lane v, register m with its output k = 8 v + m;
 // the stage across the waves makes points 2k (sum) and 2k + 1 (difference).  Wave H finishes both for m = 4 H + j, j < 4: register j holds point
-// 2k = (v << 4) | (8 H + 2 j), register 4 + j point 2k + 1.  (EO_HALF_TRADE=0: wave H holds point 2k + H of every k: register m <-> q = 2 m + H.)
+// 2k = (v << 4) | (8 H + 2 j), register 4 + j point 2k + 1.
 __global__ __launch_bounds__(256) void k_bk_to_eo(const cplx* __restrict__ src, cplx* __restrict__ dst, size_t polys) {
     const size_t total = polys * 1024;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t g = idx >> 10;
         const int k = (int)(idx & 1023);                 // destination: (H, register, lane)
         const int H = k >> 9, m = (k >> 6) & 7, lane = k & 63;
-#if EO_HALF_TRADE
         const int q = 8 * H + 2 * (m & 3) + (m >> 2);
-#else
-        const int q = 2 * m + H;
-#endif
         dst[idx] = src[g * 1024 + (size_t)q * 64 + lane];
     }
 }
@@ -164,7 +137,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     unsigned char* gbase = smem + EoLds::TW + (size_t)slot * EoLds::gate_bytes(a.npad);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
     uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
-    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + HalvesLds::abar_bytes(a.npad));
+    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + EoLds::abar_bytes(a.npad));
     double* xb1 = xb0 + 2 * G::XSLOTS;
     double* wbuf = H ? xb1 : xb0;     // the buffer pair this wave owns (writes next); ownership swaps after every trade
     double* rbuf = H ? xb0 : xb1;     // the partner's (read after its arrival)
@@ -182,13 +155,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     // wave) a raise as its own statement behind each of the eight waits costs 15-30 spilled registers, whose reloads queue with the key rows;
     // inside the wait's own assembly statement (pair_wait_opaque_prio3) it costs none: 16.17 -> 15.49 ms per 1024 gates, and the parity split
     // then beats the top-bit split (15.69).  At 1-2 gates per workgroup (512 registers, nothing spills) the separate statement measured
-    // faster (10.66 vs 10.89 ms per 512 gates).  EO_STAIRS: -1 = that choice by shape (default), 0 = no staircase, 1 = separate raise,
-    // 5 = fused raise; measured in profiles/r04/n2048_parity_split_ab.log.
-    constexpr int STAIRS = EO_STAIRS < 0 ? (GATES >= 3 ? 5 : 1) : EO_STAIRS;
-    auto eo_prio = [&](auto level) { if constexpr (STAIRS != 0) __builtin_amdgcn_s_setprio(decltype(level)::value); };
+    // faster (10.66 vs 10.89 ms per 512 gates).  Measured in profiles/r04/n2048_parity_split_ab.log.
+    constexpr bool FUSED_RAISE = GATES >= 3;
+    auto eo_prio = [&](auto level) { __builtin_amdgcn_s_setprio(decltype(level)::value); };
 #define EO_STEP(k) eo_prio(std::integral_constant<int, k>{})
     auto eo_wait = [&]() {
-        if constexpr (STAIRS == 5) pair_wait_opaque_prio3(partner_flag, sync_k);
+        if constexpr (FUSED_RAISE) pair_wait_opaque_prio3(partner_flag, sync_k);
         else { pair_wait_opaque(partner_flag, sync_k); EO_STEP(3); }
     };
 #define EO_WAIT() eo_wait()
@@ -234,7 +206,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (H) __builtin_amdgcn_s_setprio(EO_PRIO_B);
+    if (H) __builtin_amdgcn_s_setprio(0);
 #ifdef RTFHE_WG_STAMPS
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define EO_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -243,7 +215,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
 #define EO_STAMP(k) do { } while (0)
 #endif
 
-#if EO_HALF_TRADE
     // The size-2 stage across the waves, forward (the LAST stage: sub-network outputs out_E[k], out_O[k] -> points 2k = out_E + out_O, 2k + 1 =
     // out_E + (-out_O)).  A lane holds k = 8 v + m, m < 8, of its parity.  The even wave finishes both points for m < 4, the odd wave for m >= 4:
     // each sends the four values the other needs and receives four -- half the LDS traffic of "every wave finishes its parity of every k", the
@@ -283,24 +254,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
 #pragma unroll
         for (int j = 0; j < R / 2; j++) { re[RECV + j] = lds_ld(&rb[ln + 64 * j]); im[RECV + j] = lds_ld(&rb[G::XSLOTS + ln + 64 * j]); }
     };
-#else
-    // one row's cross-wave size-2 stage after the trade: mine / partner's are out_H[k], point 2k = out_0 + out_1, point 2k+1 = out_0 + (-out_1)
-    auto cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) {
-        if constexpr (!decltype(odd)::value) {
-#pragma unroll
-            for (int m = 0; m < R; m++) { re[m] = re[m] + lds_ld(&rb[ln + 64 * m]); im[m] = im[m] + lds_ld(&rb[G::XSLOTS + ln + 64 * m]); }
-        } else {
-#pragma unroll
-            for (int m = 0; m < R; m++) { re[m] = lds_ld(&rb[ln + 64 * m]) + (-re[m]); im[m] = lds_ld(&rb[G::XSLOTS + ln + 64 * m]) + (-im[m]); }
-        }
-    };
-    auto cross_write = [&](auto, const double (&re)[R], const double (&im)[R], double* wb, int ln) {
-#pragma unroll
-        for (int m = 0; m < R; m++) { lds_st(&wb[ln + 64 * m], re[m]); lds_st(&wb[G::XSLOTS + ln + 64 * m], im[m]); }
-    };
-    auto inv_cross_write = [&](auto odd, double (&re)[R], double (&im)[R], double* wb, int ln) { cross_write(odd, re, im, wb, ln); };
-    auto inv_cross_read = [&](auto odd, double (&re)[R], double (&im)[R], const double* rb, int ln) { cross_read(odd, re, im, rb, ln); };
-#endif
 
     // The whole step loop exists twice, once per parity, chosen ONCE (the waves of a workgroup meet at no barrier inside it): with the parity a
     // compile-time constant each copy is straight-line code.  A wave-uniform branch on H around the few places that differ (the size-4 half
@@ -376,7 +329,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             fetch(bA, i, rc0);                          // (row 0, c0): in flight under pass 3 and the trades
             // pass 3 row by row; a row's values go to the partner right behind it and the NEXT row's pass 3 (for the last row: the first
             // multiply-accumulates) runs between the arrival flag and the wait.  The buffers swap owners after every trade (ping-pong, see
-            // k_bootstrap_halves): row 0 is written to my buffer, row 1 to the one I read row 0 from, row 2 to the one I read row 1 from.
+            // the header): row 0 is written to my buffer, row 1 to the one I read row 0 from, row 2 to the one I read row 1 from.
             Tw<6> w3;
             w3.load(tw_p3, 1);
             EO_STEP(0);
@@ -407,7 +360,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
         // inverse: the size-2 stage across the waves comes FIRST (decimation in time), then this parity's sub-network, untwist, truncate, += acc
         // At 1-3 gates per workgroup the two components are two copies of the code (no selects of the 32 accumulator registers: 0.5-1.1 % faster,
         // profiles/r04/n2048_unrolled_components_ab.log); at 4 the copy measured +-0 and the loop keeps 11 KiB of instruction cache free.
-        constexpr int COMP_COPIES = EO_COMP_COPIES ? EO_COMP_COPIES : (GATES <= 3 ? 2 : 1);
+        constexpr int COMP_COPIES = GATES <= 3 ? 2 : 1;
 #pragma unroll COMP_COPIES
         for (int comp = 0; comp < 2; comp++) {
             if (COMP_COPIES == 2) __builtin_amdgcn_sched_barrier(0);      // the copies one after the other, not interleaved
@@ -441,18 +394,13 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
                     // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395); the 2/N of fft_processor_spqlios.cpp:158 is in the table
                     const double rc = vr * wt.w[m].x, ic = vi * wt.w[m].x, rs = vr * wt.w[m].y, is = vi * wt.w[m].y;
                     const int c = 2 * (lane + 64 * m) + H;
-#if EO_DS_ADD         // the update as ds_add_u32: no read-back through the wave (14.59 -> 14.52 ms per 1024 gates, 9.98 -> 9.91 per 512; the latency kernel, whose
                       // lone waves wait on the add's completion, loses 2 % with it)
                     __hip_atomic_fetch_add(&poly[c], trunc_to_torus(rc - is), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     __hip_atomic_fetch_add(&poly[c + P], trunc_to_torus(ic + rs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-                    poly[c] += trunc_to_torus(rc - is);
-                    poly[c + P] += trunc_to_torus(ic + rs);
-#endif
                 }
             }
             // (my accumulator words are published by my next arrival -- the other component's trade / the next step's first row -- which the
-            // partner waits for before it gathers them; see k_bootstrap_halves)
+            // partner waits for before it gathers them)
             EO_STAMP(5);
         }
     }

@@ -31,9 +31,6 @@
 // a point on -- 1 = the end of its slot P, 2 = of its slot Q, 3 = its second exchange (k_bootstrap_pair's schedule), 4 = its last forward trade; 0 = no
 // priorities.  Measured (profiles/r04/n2048_four_waves_priority_ab.log): 512 gates 8.12 (0) / 7.70-7.86 (1) / 7.83 (2) / 7.91 (3) / 7.84 (4) ms, 300
 // gates 7.91 / 7.25-7.29 / 7.29 / 7.42 / 7.11 ms.
-#ifndef EO4_PRIO
-#define EO4_PRIO 4
-#endif
 // (The wave-private exchanges as one 16-byte LDS access per complex value at one gate per workgroup, every wave alone on its SIMD: 5.82 -> 5.96 ms.)
 
 namespace rtfhe {
@@ -41,9 +38,9 @@ namespace rtfhe {
 struct Eo4Lds {
     typedef Geo<10> G;
     static constexpr size_t TW = EoLds::TW;
-    static constexpr size_t XB = HalvesLds::XB;
+    static constexpr size_t XB = EoLds::XB;
     static constexpr size_t FLAGS = 32;       // per gate: 4 trade counters + 4 hand-off counters
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + HalvesLds::abar_bytes(npad) + 4 * XB + FLAGS; }
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + EoLds::abar_bytes(npad) + 4 * XB + FLAGS; }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
@@ -53,7 +50,6 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
     typedef Geo<10> G;   // geometry of a parity's 512-point sub-network
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3, "three digit rows of a polynomial are transformed side by side");
-    static_assert(EO_HALF_TRADE, "both sides of a parity must hold the same spectrum points");
     const BootstrapArgs& a = ea.b;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -80,7 +76,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
     unsigned char* gbase = smem + Eo4Lds::TW + (size_t)slot * Eo4Lds::gate_bytes(a.npad);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
     uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
-    double* xbase = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + HalvesLds::abar_bytes(a.npad));
+    double* xbase = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + EoLds::abar_bytes(a.npad));
     auto xb = [&](int s, int idx) { return xbase + (size_t)(s * 2 + idx) * 2 * G::XSLOTS; };      // the two buffers of side s
     int widx = H;                             // which of my side's buffers I own (write next); flips after every trade
     uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + Eo4Lds::gate_bytes(a.npad) - Eo4Lds::FLAGS);
@@ -188,7 +184,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        if constexpr (EO4_PRIO != 0 && GATES == 2) __builtin_amdgcn_s_setprio(SIDE == 0 ? 2 : 1);
+        if constexpr (GATES == 2) __builtin_amdgcn_s_setprio(SIDE == 0 ? 2 : 1);
         double* wbuf = xb(SIDE, widx);            // the buffer I own (write next)
         double* rbuf = xb(SIDE, widx ^ 1);        // my parity partner's (read after its arrival)
         int ln = lane0;
@@ -239,7 +235,6 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
                 exchange<10, 2, 3, true>(yr[jj], yi[jj], wbuf, ln);
             }
         }
-        if constexpr (EO4_PRIO == 3 && GATES == 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
         fetch(bA, i, rc0);                          // (first row, component 0): in flight under pass 3 and the trades
         {   // pass 3 row by row; a row goes to the parity partner right behind it, the NEXT row's pass 3 runs between the arrival flag and the wait
             Tw<6> w3;
@@ -253,7 +248,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
             EO4_WAIT(); cross_read(parity, yr[1], yi[1], wbuf, ln);
             cross_write(parity, yr[2], yi[2], wbuf, ln); EO4_ARRIVE();
         }
-        if constexpr (EO4_PRIO == 4 && GATES == 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr (GATES == 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
         fetch(bB, i, rc0 + 2);                      // (second row, component 0)
         EO4_WAIT(); cross_read(parity, yr[2], yi[2], rbuf, ln);
         widx ^= 1;                                  // three trades: I now own the buffer I read last
@@ -269,7 +264,6 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
             mac_row<R>(sre, sim, bB, yr[1], yi[1]); fetch(bB, i, rc0 + 1);
             mac_row<R>(sre, sim, bA, yr[2], yi[2]); fetch(bA, i, rc0 + 3);
             put(mine, sre, sim, ln);                                                  // hand0
-            if constexpr (EO4_PRIO == 1 && GATES == 2) __builtin_amdgcn_s_setprio(0);
             EO4_HANDOFF();
 #pragma unroll
             for (int m = 0; m < R; m++) { sre[m] = 0.0; sim[m] = 0.0; }
@@ -277,7 +271,6 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
             mac_row<R>(sre, sim, bA, yr[1], yi[1]);
             mac_row<R>(sre, sim, bB, yr[2], yi[2]);
             put(theirs, sre, sim, ln);                                                // hand1 (side 1 has finished its transforms: hand-off 1)
-            if constexpr (EO4_PRIO == 2 && GATES == 2) __builtin_amdgcn_s_setprio(0);
             EO4_HANDOFF();
             get(mine, sre, sim, ln);                                                  // component 0, rows 0..5
         } else {

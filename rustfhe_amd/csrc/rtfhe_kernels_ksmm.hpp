@@ -41,13 +41,10 @@ struct KsMmArgs {
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 // grid: x = (mg * splitk + slice) * colgroups + cg; one wave per block
-#ifndef KSMM_MT
-#define KSMM_MT 4
-#endif
 template <int KS_T, int KS_BB>
 __global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
     static_assert(KS_T == 8 && KS_BB == 2, "operand packing: 4 levels x 4 digit values per 16-byte operand chunk");
-    constexpr int MT = KSMM_MT, PF = 4;       // gate tiles per wave; K-steps of key operands in flight
+    constexpr int MT = 4, PF = 4;       // gate tiles per wave; K-steps of key operands in flight
     constexpr uint32_t ROUND = 1u << (32 - KS_T * KS_BB - 1);
     const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
     const int cg = blockIdx.x % a.colgroups, rest = blockIdx.x / a.colgroups;

@@ -170,12 +170,6 @@ struct NttPairLds {
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
 };
 
-#ifndef NTT_PAIR_LOWER_AT
-#define NTT_PAIR_LOWER_AT 2
-#endif
-#ifndef NTT_PAIR_RAISE_AT
-#define NTT_PAIR_RAISE_AT 8
-#endif
 
 template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
 __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const NttBootstrapArgs args) {
@@ -208,13 +202,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
     if (lane == 0) flags[side] = 0u;
     [[maybe_unused]] const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side);
     [[maybe_unused]] const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side));
-#if defined(NTT_PAIR_FLAG_SYNC)
-    constexpr bool FLAG_SYNC = true;
-#elif defined(NTT_PAIR_WG_BARRIER)
-    constexpr bool FLAG_SYNC = false;
-#else
     constexpr bool FLAG_SYNC = GATES <= 2;      // measured: 512 gates 6.93 -> 6.69 ms; 768 gates 10.26 -> 10.49 (slower); 1024 gates equal
-#endif
     uint32_t* poly = accbuf + side * N;
     const int n = a.n;
     {
@@ -235,19 +223,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
         }
     }
     wave_lds_sync();
-    // priority schedule as in k_bootstrap_pair: side 1 at 1, side 0 at 2 from NTT_PAIR_RAISE_AT to NTT_PAIR_LOWER_AT, else 0
+    // priority schedule as in k_bootstrap_pair: side 1 at 1, side 0 at 2 from RAISE_AT to LOWER_AT, else 0
+    constexpr int LOWER_AT = 2, RAISE_AT = 8;
     auto prio_point = [&](int point) {   // `point` may be a run-time (scalar) value: selection by scalar ALU, the branch stays inside the asm
-#ifdef NTT_PAIR_STAIRS   // A/B: the symmetric "laggard first" staircase of the N = 2048 kernels (both sides run the same code here): 3 through the swap and the
-                         // inverse, 2 from the end of a step (gather, first row), 1 after the first row, 0 after the second
-        const int lvl = __builtin_amdgcn_readfirstlane((point == 7 || point == 8) ? 3 : point == 9 ? 2 : point == 1 ? 1 : point == 3 ? 0 : 4);
-        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc0 1f\n\ts_setprio 0\n1:\n\t"
-                     "s_cmp_eq_u32 %0, 1\n\ts_cbranch_scc0 2f\n\ts_setprio 1\n2:\n\t"
-                     "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc0 3f\n\ts_setprio 2\n3:\n\t"
-                     "s_cmp_eq_u32 %0, 3\n\ts_cbranch_scc0 4f\n\ts_setprio 3\n4:" ::"s"(lvl) : "scc");
-        return;
-#endif
-        const int lower = __builtin_amdgcn_readfirstlane((point == NTT_PAIR_LOWER_AT) & (side == 0));
-        const int raise = __builtin_amdgcn_readfirstlane((point == NTT_PAIR_RAISE_AT) & (side == 0));
+        const int lower = __builtin_amdgcn_readfirstlane((point == LOWER_AT) & (side == 0));
+        const int raise = __builtin_amdgcn_readfirstlane((point == RAISE_AT) & (side == 0));
         asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(lower) : "scc");
         asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(raise) : "scc");
     };

@@ -22,9 +22,6 @@
 // twiddle is zeta_1^-1 = -zeta_1.  With 16 KiB of accumulator per gate four gates per CU fit (154 KiB).
 #pragma once
 
-#ifndef NH_SB
-#define NH_SB __builtin_amdgcn_sched_barrier(0)
-#endif
 
 #include "rtfhe_kernels_ntt.hpp"
 
@@ -75,17 +72,9 @@ template <int L, int BGBIT, bool CMUX, bool PAIRSYNC = false>
 __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, int r, const __amdgpu_buffer_rsrc_t bk_rsrc, int bk_off,
                                                 const NttHalvesTables& t, double* myx, const double* otx,      /* the partner writes otx: no restrict */
                                                 int lane0, int H, unsigned my_flag = 0, unsigned partner_flag = 0, unsigned* sync_k = nullptr) {
-    // -DNTTH_STAIRS (A/B): the priority staircase of the FFT kernels at N = 2048 -- priority 3 after every synchronisation, falling row by row
-    // through the forward transforms, so that whichever half is behind is favoured
-#ifdef NTTH_STAIRS
-#define NTTH_PRIO(k) __builtin_amdgcn_s_setprio(k)
-#else
-#define NTTH_PRIO(k) do { } while (0)
-#endif
     auto halves_sync = [&]() {
         if constexpr (PAIRSYNC) pair_sync(my_flag, partner_flag, ++*sync_k);
         else lds_barrier();
-        NTTH_PRIO(3);
     };
     constexpr int LOGN = 11, N = 2048, HN = 1024, R = ntt::R;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
@@ -118,7 +107,6 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
             double x[R];
-            if (jj == 0) NTTH_PRIO(2); else if (jj == 1) NTTH_PRIO(1); else NTTH_PRIO(0);
             if (H) {        // branch on the half around the loop (a select inside it computes both sums)
 #pragma unroll
                 for (int m = 0; m < R; m++)
@@ -135,18 +123,18 @@ __device__ __forceinline__ void ntt_halves_step(uint32_t* __restrict__ accbuf, i
             // front cost 30 spilled registers: 45.0 vs 42.4 ms per 1024 gates)
             const int s0off = __builtin_amdgcn_readfirstlane(bk_off + (((h * L + jj) * 2 + 0) * 2 + H) * ntt::N * 8);
             const int s1off = s0off + 2 * ntt::N * 8;
-            NH_SB;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < R / 2; q++) b0[q] = ld2(lane * 16 + q * 1024, s0off);
-            NH_SB;
+            __builtin_amdgcn_sched_barrier(0);
             ntt::forward_b(x, t.fwd, myx, lane);
-            NH_SB;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < R / 2; q++) b1[q] = ld2(lane * 16 + q * 1024, s1off);
-            NH_SB;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < R / 2; q++) { s0[2 * q] += ntt::modmul(x[2 * q], b0[q].x);     s0[2 * q + 1] += ntt::modmul(x[2 * q + 1], b0[q].y); }
-            NH_SB;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < R / 2; q++) { s1[2 * q] += ntt::modmul(x[2 * q], b1[q].x);     s1[2 * q + 1] += ntt::modmul(x[2 * q + 1], b1[q].y); }
         }
@@ -214,11 +202,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
     double* myx = H ? xb1 : xb0;
     const double* otx = H ? xb0 : xb1;
     // arrival counters of the two halves of this gate (zeroed before the start-up barriers)
-#ifdef NTT_HALVES_WG_BARRIER      // A/B: the workgroup-wide barrier (round 2)
-    constexpr bool PAIRSYNC = false;
-#else
     constexpr bool PAIRSYNC = GATES >= 2;     // 1024 gates 31.30 -> 31.06 ms, 512 gates 19.70 -> 19.25; one gate per workgroup 18.22 -> 18.34: off there
-#endif
     uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + NttHalvesLds::gate_bytes(a.npad) - NttHalvesLds::FLAGS);
     if (lane0 == 0) flags[H] = 0u;
     const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + H);

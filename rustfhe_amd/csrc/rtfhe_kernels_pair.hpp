@@ -34,44 +34,18 @@
 
 #include "rtfhe_kernels.hpp"
 
-// side 0's priority schedule (see prio_point in k_bootstrap_pair); overridable for A/B builds
-#ifndef PAIR_LOWER_AT
-#define PAIR_LOWER_AT 2
-#endif
-#ifndef PAIR_RAISE_AT
-#define PAIR_RAISE_AT 10     // round 3 (unpaired LDS exchanges, key switch out of the kernel): raising at the END of the step instead of
-#endif                       // before barrier 2 -- side 0's inverse then runs at low priority under side 1's R + inverse -- 6.81 -> 6.67 ms
-                             // per 1024 gates (profiles/r03/pair_priority_grid.log)
-// The pass-3 butterfly whose twiddle is exactly (1, 0) without its multiplies (fwd_stage_tw, TRIV0) and slot P's first row without its
-// "+0.0 +": 64 fewer FP64 instructions per CMUX, the same torus words.  History: with round 2's priority points this measured +-0 (7.122 vs
-// 7.122 ms per 1024 gates); with round 3's (raise at end of step) it is worth 3.5 % (7.22 -> 7.04 -> 6.97 ms on a slow box,
-// profiles/r03/pair_unit_twiddle_first_row_ab.log).  -DRTFHE_BOOT_TRIV=0 / -DPAIR_ZERO_FOLD: the reference's operation list as it stands.
-#ifndef PAIR_TRIV
-#define PAIR_TRIV BOOT_TRIV
-#endif
-// the wave-private exchanges of the transforms: 0 = real and imaginary parts as 8-byte accesses of their own, 1 = one 16-byte LDS access per complex
-// value (A/B builds).  Measured (profiles/r04/pair_exchange_16byte_ab.log): SQ_INSTS_LDS 462 M -> 295 M per launch, SQ_LDS_IDX_ACTIVE unchanged
-// (1.53 G: the same LDS-pipe time), no bank conflicts -- and 6.644 -> 6.685 ms per 1024 gates, 4.19 -> 4.27 per 512: the LDS pipe's time is what the
-// exchanges cost, not their instruction slots (and the 16-byte register tuples cost the allocator 21 spilled registers at 4 gates per workgroup).
-#ifndef PAIR_X128
-#define PAIR_X128 0
-#endif
+// What was tried on this kernel and measured slower (other priority schedules, a split-phase first hand-off, 8-byte hand-offs, 16-byte exchanges,
+// the symmetric priority staircase, other wave placements) is recorded in profiles/HISTORY.md; the code below is what ships.
 
 namespace rtfhe {
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
 // spaces, i.e. s_waitcnt vmcnt(0): it would wait for the key rows prefetched across it.  Hand-offs here go through LDS.
 __device__ __forceinline__ void lds_barrier() {
-#ifdef ABL_NOBAR      // timing ablation only (wrong results)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
-// the first row of a fold: the reference adds it to FrrSeries::zero() (trgsw.rs:290-299); +0.0 + x == x for every x except that
-// it turns a -0.0 into +0.0, and the sign of a zero never reaches a torus word (see fwd_stage_tw in rtfhe_device.hpp)
-// Synchronisation of the TWO waves of one gate only (used at 2 / 3 gates per workgroup; -DPAIR_FLAG_SYNC / -DPAIR_WG_BARRIER force one form).  s_barrier is workgroup-wide although the four gates of a
+// Synchronisation of the TWO waves of one gate only (used at 2 / 3 gates per workgroup).  s_barrier is workgroup-wide although the four gates of a
 // workgroup share nothing after start-up; the phase stamps show BOTH sides of a pair ~1.1 k cycles "at barrier 1", which looked like the pairs
 // waiting for the slowest gate.  Here each side publishes an arrival counter in LDS after its hand-off stores and polls its partner's (DS
 // instructions of a wave execute in order, so a partner that sees counter >= k also sees the stores issued before it; no fence, which would wait
@@ -134,6 +108,8 @@ __device__ __forceinline__ void pair_wait_opaque_prio3(unsigned partner_flag_add
         : "memory", "scc");
 }
 
+// the first row of a fold: the reference adds it to FrrSeries::zero() (trgsw.rs:290-299); +0.0 + x == x for every x except that
+// it turns a -0.0 into +0.0, and the sign of a zero never reaches a torus word (see fwd_stage_tw in rtfhe_device.hpp)
 template <int R>
 __device__ __forceinline__ void mac_row_first(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&re)[R], const double (&im)[R]) {
 #pragma unroll
@@ -175,26 +151,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     static_assert(L == 3, "three rows per side are held in registers");
     // the two waves of a gate synchronise through the workgroup barrier when the workgroup is full (4 gates: 6.74 vs 6.76 ms with pair_sync) and
     // with each other only when it is not (2 / 3 gates per workgroup: 4.34 vs 4.37 ms at 512 gates, 6.14 vs 6.20 at 768)
-#if defined(PAIR_FLAG_SYNC)
-    constexpr bool FLAG_A = true, FLAG_B = true;
-#elif defined(PAIR_WG_BARRIER)
-    constexpr bool FLAG_A = false, FLAG_B = false;
-#elif defined(PAIR_SYNC_MIXED)
-    constexpr bool FLAG_A = true, FLAG_B = false;
-#else
     constexpr bool FLAG_A = GATES < 4, FLAG_B = GATES < 4;
-#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifndef PAIR_MAP
-#define PAIR_MAP 0
-#endif
-    // which gate and side a wave serves.  Waves go to the SIMDs round robin (wave w on SIMD w % 4).  0: the two sides of a gate share a SIMD (waves w, w + GATES);
-    // 1 (A/B, 4 gates): partners on neighbouring SIMDs, a SIMD hosts the same side of two gates; 2 (A/B, 4 gates): partners on neighbouring SIMDs, a SIMD
-    // hosts side 0 of one gate and side 1 of another
-    const int slot = (PAIR_MAP == 1 && GATES == 4) ? wave / 2 : (PAIR_MAP == 2 && GATES == 4) ? 2 * ((wave & 3) >> 1) + (wave >> 2) : wave % GATES;
-    const int side = (PAIR_MAP == 1 && GATES == 4) ? wave % 2 : (PAIR_MAP == 2 && GATES == 4) ? ((wave & 1) ^ (wave >> 2)) : wave / GATES;
+    // which gate and side a wave serves.  Waves go to the SIMDs round robin (wave w on SIMD w % 4): the two sides of a gate share a SIMD (waves w,
+    // w + GATES) -- they are in complementary phases, each other's best SIMD partner (profiles/r03/wave_placement_on_simds_ab.log)
+    const int slot = wave % GATES;
+    const int side = wave / GATES;
     cplx* tw = reinterpret_cast<cplx*>(smem);
     for (int idx = tid; idx < G::TW_TOTAL; idx += NT) tw[idx] = a.tw[idx];
     const cplx* twf = tw;
@@ -265,11 +229,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(a.bk), 0, 0x7fffffff, 0x00020000);
     const int lane16 = lane * 16;
     auto fetch = [&](cplx (&dst)[R], int step, int rc) {
-#ifdef ABL_BKHOT      // timing ablation only (wrong results): every key row load hits the same (cache-resident) row
-        const size_t row = (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64 + 0 * step;
-#else
         const size_t row = (size_t)step * trgsw_cplx + (size_t)((side * L + rc % L) * 2 + rc / L) * R * 64;
-#endif
         const int s_lo = __builtin_amdgcn_readfirstlane((int)(row * sizeof(cplx)));
         const int s_hi = s_lo + (R / 2) * 64 * (int)sizeof(cplx);
         __builtin_amdgcn_sched_barrier(0);
@@ -291,56 +251,17 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     }
     // Priority schedule.  Of two waves that both have work a SIMD runs one at (nearly) full speed and the other on the
     // leftovers (s_setprio selects which), so with fixed priorities the favoured side reaches every barrier early and the
-    // SIMD then runs a single wave.  Side 1 stays at priority 1; side 0 runs at 2 from
-    // PAIR_RAISE_AT to PAIR_LOWER_AT and at 0 for the rest of the step, which splits the time between the barriers
-    // about evenly (measured: profiles/r01_pair/priority_schedule_ab.log).  Points: 0..5 after each half transform,
+    // SIMD then runs a single wave.  Side 1 stays at priority 1; side 0 runs at 2 from the end of a step (RAISE_AT) to the end of its pass 2
+    // (LOWER_AT) and at 0 for the rest of the step -- its inverse then runs at low priority under side 1's slot R + inverse -- which splits the
+    // time between the barriers about evenly (profiles/r01_pair/priority_schedule_ab.log, profiles/r03/pair_priority_grid.log; the search over
+    // every schedule these points allow: profiles/r04/pair_priority_search.log).  Points: 1 after pass 1, 2 after pass 2, 5 after pass 3,
     // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
+    constexpr int LOWER_AT = 2, RAISE_AT = 10;
     auto prio_point = [&](int point) {   // one opaque statement each: no compiler-visible control flow inside the transforms
-#ifdef PAIR_FLAT_PRIO    // A/B: no schedule, every wave at priority 1
-        return;
-#endif
-#ifdef PAIR_PRIO_RUNTIME  // tuning build (scripts/tune_prio.py): the schedule comes in a.tune, 3 bits per (side, point): 0..3 = s_setprio that level, 4..7 = leave
-        {
-            constexpr int slot_of[11] = {-1, 1, 2, -1, -1, 3, 4, 5, 6, 7, 0};     // points 10, 1, 2, 5, 6, 7, 8, 9 -> slots 0..7
-            if (slot_of[point] < 0) return;
-            const unsigned f = (unsigned)(a.tune >> (3 * (side * 8 + slot_of[point]))) & 7u;
-            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc0 1f\n\ts_setprio 0\n1:\n\t"
-                         "s_cmp_eq_u32 %0, 1\n\ts_cbranch_scc0 2f\n\ts_setprio 1\n2:\n\t"
-                         "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc0 3f\n\ts_setprio 2\n3:\n\t"
-                         "s_cmp_eq_u32 %0, 3\n\ts_cbranch_scc0 4f\n\ts_setprio 3\n4:" ::"s"(f) : "scc");
-            return;
-        }
-#endif
-#ifdef PAIR_STAIRS       // A/B: the symmetric priority staircase of the N = 2048 kernels -- both sides' priority falls 3 -> 0 along the stretch from
-                         // barrier 2 to barrier 1 (inverse + update | gather + pass 1 | pass 2 | pass 3 + slot P) and is 3 through slot Q
-        if (point == 9 || point == 7) asm volatile("s_setprio 3");
-        if (point == 10) asm volatile("s_setprio 2");
-        if (point == 1) asm volatile("s_setprio 1");
-        if (point == 2) asm volatile("s_setprio 0");
-        return;
-#endif
-#ifdef PAIR_MID_AT
-        if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
-#else
-        if (point == PAIR_LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
-#endif
-        if (point == PAIR_RAISE_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
-#ifdef PAIR_MID_AT       // A/B: a third level for side 0 (priority 1 = side 1's) from PAIR_LOWER_AT to PAIR_MID_AT, 0 after it
-        if (point == PAIR_MID_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
-#endif
-#ifdef PAIR_S1_HIGH_AT   // A/B: side 1 at priority 3 from PAIR_S1_HIGH_AT to PAIR_S1_BACK_AT (its own points), 1 otherwise
-        if (point == PAIR_S1_HIGH_AT) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 3\n1:" ::"s"(side) : "scc");
-        if (point == PAIR_S1_BACK_AT) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(side) : "scc");
-#endif
+        if (point == LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
+        if (point == RAISE_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
     };
-#ifdef PAIR_FLAT_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#else
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
-#endif
-#ifdef PAIR_PRIO_RUNTIME
-    prio_point(10);
-#endif
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
@@ -353,11 +274,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
         for (int mm = 0; mm < 2 * R; mm++) {
             const int c = ln + 64 * mm;
-#ifdef ABL_NOGATHER   // timing ablation only (wrong results)
-            u[mm] = ((own[mm] * (uint32_t)(r + c)) + M) ^ M;
-#else
             u[mm] = ((rotated_coef<LOGN>(poly, c, r) - own[mm]) + M) ^ M;
-#endif
         }
         PAIR_STAMP(0);
         double xr[L][R], xi[L][R];
@@ -369,51 +286,20 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
                 xi[jj][m] = (double)decomp_digit(u[R + m], BGBIT, jj);
             }
         }
-#ifdef PAIR_SEQUENTIAL_ROWS      // A/B: one transform after the other (round 1)
-#pragma unroll
-        for (int jj = 0; jj < L; jj++) {
-            fft_forward_a<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
-            prio_point(2 * jj);
-            fft_forward_b<LOGN, true>(xr[jj], xi[jj], twf, myx, lane);
-            prio_point(2 * jj + 1);
-            PAIR_STAMP(1 + jj);
-        }
-#else
         // the three digit rows side by side: twiddles loaded once per pass, a row's exchange in flight under the next rows' passes
         auto pp1 = [&]() { prio_point(1); };
-#ifdef PAIR_NO_INTERLEAVE     // A/B: the exchanges' DS instructions in bursts, as the compiler places them
-        fft_forward_multi_a<LOGN, L, true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
-#else
-        fft_forward_multi_a<LOGN, L, true, decltype(pp1), true, PAIR_X128 != 0>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
-#endif
+        fft_forward_multi_a<LOGN, L, true, decltype(pp1), true>(xr, xi, twf, myx, myx + G::XSLOTS, ln, pp1);
         prio_point(2);
         PAIR_STAMP(1);
-        fft_forward_multi_b<LOGN, L, PAIR_TRIV>(xr, xi, twf);
+        fft_forward_multi_b<LOGN, L, BOOT_TRIV>(xr, xi, twf);
         prio_point(5);
         PAIR_STAMP(3);
-#endif
 
         double sre[R], sim[R];
         auto zero = [&]() {
 #pragma unroll
             for (int m = 0; m < R; m++) { sre[m] = 0.0; sim[m] = 0.0; }
         };
-#ifdef PAIR_HAND_B64      // A/B: the hand-offs as 8-byte accesses, never paired (lds_st / lds_ld), real parts then imaginary parts: [2][R][64] doubles
-        auto put = [&](cplx* h) {
-            double* d = reinterpret_cast<double*>(h - lane) + lane;
-#pragma unroll
-            for (int m = 0; m < R; m++) lds_st(&d[m * 64], sre[m]);
-#pragma unroll
-            for (int m = 0; m < R; m++) lds_st(&d[R * 64 + m * 64], sim[m]);
-        };
-        auto get = [&](const cplx* h) {
-            const double* d = reinterpret_cast<const double*>(h - lane) + lane;
-#pragma unroll
-            for (int m = 0; m < R; m++) sre[m] = lds_ld(&d[m * 64]);
-#pragma unroll
-            for (int m = 0; m < R; m++) sim[m] = lds_ld(&d[R * 64 + m * 64]);
-        };
-#else
         auto put = [&](cplx* h) {
 #pragma unroll
             for (int m = 0; m < R; m++) h[m * 64] = make_double2(sre[m], sim[m]);
@@ -422,35 +308,18 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
 #pragma unroll
             for (int m = 0; m < R; m++) { const cplx v = h[m * 64]; sre[m] = v.x; sim[m] = v.y; }
         };
-#endif
 
-        // slot P (side 0): component 0 over rows 0..2 from +0.0
+        // slot P (side 0): component 0 over rows 0..2 from +0.0 (the first row without its "+0.0 +", see mac_row_first: with the unit-twiddle
+        // butterflies 64 fewer FP64 instructions per CMUX, the same torus words, 3.5 % -- profiles/r03/pair_unit_twiddle_first_row_ab.log)
         if (side == 0) {
-#if defined(PAIR_ZERO_FOLD) || !RTFHE_BOOT_TRIV
-            zero();
-            mac_row<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
-#else
             mac_row_first<R>(sre, sim, bB, xr[0], xi[0]); fetch(bB, i, 2);
-#endif
             mac_row<R>(sre, sim, bA, xr[1], xi[1]); fetch(bA, i, 3);
             mac_row<R>(sre, sim, bB, xr[2], xi[2]); fetch(bB, i, 4);
             put(hand0);
         }
         prio_point(6);
         PAIR_STAMP(4);
-#ifdef PAIR_EARLY_Q
-        // Split-phase hand-off 1 (round 4).  What each side needs at this point differs: side 1 needs hand0 (side 0's slot P) BEFORE its slot Q;
-        // side 0 needs nothing for its slot-Q arithmetic (its own rows, its own key rows) -- only the buffer its result goes to (hand1 = side
-        // 1's exchange buffers) must be idle, i.e. side 1 must have finished its transforms, BEFORE the put.  Both arrive here; side 1 waits
-        // here, side 0 waits in front of its put.  The stamps of round 3 had side 0 parked 2.5-2.8 k cycles per step at the barrier that stood
-        // here while side 1 (the lower-priority wave during the transforms) ran alone.
-        // (the same code on both sides -- a wait behind a branch on the side made the allocator spill 91 registers: the side that need not wait
-        // polls its OWN counter, which it has just advanced)
-        pair_arrive(my_flag, 2u * (unsigned)i + 1u);
-        pair_wait_opaque(side ? partner_flag : my_flag, 2u * (unsigned)i + 1u);
-#else
         if constexpr (FLAG_A) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u); else lds_barrier();
-#endif
         prio_point(7);
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
@@ -461,18 +330,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         mac_row<R>(sre, sim, bA, xr[0], xi[0]); fetch(bA, i, side ? 2 : 5);
         mac_row<R>(sre, sim, bB, xr[1], xi[1]); fetch(bB, side ? i : nxt, side ? 3 : 0);
         mac_row<R>(sre, sim, bA, xr[2], xi[2]); fetch(bA, side ? i : nxt, side ? 4 : 1);
-#ifdef PAIR_EARLY_Q
-        pair_wait_opaque(side ? my_flag : partner_flag, 2u * (unsigned)i + 1u);     // side 0: hand1 is side 1's exchange buffer pair, idle once side 1 has arrived
-#endif
         put(side ? hand0 : hand1);
         prio_point(8);
         PAIR_STAMP(6);
-#ifdef PAIR_EARLY_Q
-        pair_arrive(my_flag, 2u * (unsigned)i + 2u);
-        pair_wait_opaque(partner_flag, 2u * (unsigned)i + 2u);
-#else
         if constexpr (FLAG_B) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();
-#endif
         prio_point(9);
         PAIR_STAMP(7);
         // slot R (side 1): component 1 over rows 3..5 on top of side 0's partial sum; side 0 picks up the finished s0
@@ -487,7 +348,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         PAIR_STAMP(8);
 
         // the 2/N input scaling of the reference (fft_processor_spqlios.cpp:158) is folded into the untwist twiddles
-        fft_inverse<LOGN, PAIR_X128 ? 2 : 1, PAIR_TRIV>(sre, sim, twi, twi, myx, lane);
+        fft_inverse<LOGN, 1, BOOT_TRIV>(sre, sim, twi, twi, myx, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
@@ -501,9 +362,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         PAIR_STAMP(9);
     }
     __builtin_amdgcn_s_setprio(0);
-#ifdef ABL_NOKS       // timing ablation only (wrong results): no sample extract / key switch
-    if (a.steps >= 0) return;
-#endif
 #ifdef RTFHE_WG_STAMPS
     if (a.dbg && blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 16; k++) a.dbg[wave * 16 + k] = tsum[k];

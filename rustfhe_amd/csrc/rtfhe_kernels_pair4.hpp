@@ -26,9 +26,6 @@
 // priorities at two gates per workgroup (the two sides of a parity share a SIMD): side 1 at 1, side 0 at 2 from the start of a step and at 0 from a
 // point on -- 4 = its last forward trade (default), 5 = the end of the passes that use the exchange buffer, 6 = the end of its slot P; 0 = none;
 // 1 = side 0 at 2 throughout.  Measured (profiles/r04/pair4_ab.log): 512 gates 4.34 (0) / 4.35 (1) / 4.06 (4) ms.
-#ifndef PAIR4_PRIO
-#define PAIR4_PRIO 4
-#endif
 // (at three gates per workgroup, where the two sides of a parity do not always share a SIMD, the same schedule: 5.83 vs 6.04 ms per 768 gates without)
 
 namespace rtfhe {
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
-        if constexpr (PAIR4_PRIO != 0 && GATES >= 2) __builtin_amdgcn_s_setprio(SIDE == 0 ? 2 : 1);
+        if constexpr (GATES >= 2) __builtin_amdgcn_s_setprio(SIDE == 0 ? 2 : 1);
         cplx* wbuf = xb(SIDE, widx);              // the buffer I own (write next)
         cplx* rbuf = xb(SIDE, widx ^ 1);          // my parity partner's (read after its arrival)
         int ln = lane0;
@@ -236,13 +233,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
         // twist and the parity's sub-network of the three rows (spqlios-fft-impl.cpp:496-603): first the passes that need the exchange buffer, for all
         // rows; then row by row the last pass (registers only) with the row's trade behind it -- the NEXT row's last pass runs between the arrival
         // flag and the wait
-#ifdef PAIR4_ROWS_IN_TURN     // A/B: one row's three passes after the other's
-#pragma unroll
-        for (int jj = 0; jj < L; jj++) sub256_forward_a<QT, Q4NoHook, true>(yr[jj], yi[jj], qf, wbuf, ln);
-#else
         sub256_forward_a_multi<L, true>(yr, yi, qf, wbuf, ln);
-#endif
-        if constexpr (PAIR4_PRIO == 5 && GATES == 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
         sub256_forward_b<ODD, BOOT_TRIV>(yr[0], yi[0], qf);
         cross_write(parity, yr[0], yi[0], wbuf, ln); P4_ARRIVE();
         sub256_forward_b<ODD, BOOT_TRIV>(yr[1], yi[1], qf);
@@ -251,7 +242,7 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
         sub256_forward_b<ODD, BOOT_TRIV>(yr[2], yi[2], qf);
         P4_WAIT(); cross_read(parity, yr[1], yi[1], wbuf, ln);
         cross_write(parity, yr[2], yi[2], wbuf, ln); P4_ARRIVE();
-        if constexpr (PAIR4_PRIO == 4 && GATES >= 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr (GATES >= 2 && SIDE == 0) __builtin_amdgcn_s_setprio(0);
         fetch(bB, i, rc0 + 2);                      // (second row, component 0)
         P4_WAIT(); cross_read(parity, yr[2], yi[2], rbuf, ln);
         widx ^= 1;                                  // three trades: I now own the buffer I read last
@@ -267,7 +258,6 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_pair4(const Pair4A
             mac_row<R>(sre, sim, bB, yr[1], yi[1]); fetch(bB, i, rc0 + 1);
             mac_row<R>(sre, sim, bA, yr[2], yi[2]); fetch(bA, i, rc0 + 3);
             put(mine, sre, sim, ln);                                                  // hand0
-            if constexpr (PAIR4_PRIO == 6 && GATES == 2) __builtin_amdgcn_s_setprio(0);
             P4_HANDOFF();
 #pragma unroll
             for (int m = 0; m < R; m++) { sre[m] = 0.0; sim[m] = 0.0; }

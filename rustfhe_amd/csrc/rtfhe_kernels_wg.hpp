@@ -30,17 +30,8 @@
 #include "rtfhe_sub256.hpp"
 
 // priority of the half-row waves during the F phase (they share a SIMD with a whole-row wave each: half the arithmetic, one more LDS round trip)
-#ifndef WG_HALF_PRIO
-#define WG_HALF_PRIO 0
-#endif
 // ... and from its k-th exchange on (0 = never changed).  Measured (profiles/r04/latency_half_row_priority_ab.log): raised for the whole phase +7 % time;
 // raised to 1 behind the second exchange -0.6 % (one gate) / -2 % (256 gates)
-#ifndef WG_HALF_PRIO_AT
-#define WG_HALF_PRIO_AT 2
-#endif
-#ifndef WG_HALF_PRIO_THEN
-#define WG_HALF_PRIO_THEN 1
-#endif
 
 namespace rtfhe {
 
@@ -113,16 +104,6 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     // Software-pipelined: the values of step i + 1 are requested at the start of step i's I phase (6 of the 8 waves idle
     // there) and have landed by the barrier that ends it.
     cplx bkv[ROWS][2];
-#ifdef WG_BK_POINTER_LOADS
-    auto load_bk = [&](int step, cplx (&dst)[ROWS][2]) {
-        const cplx* bk_i = a.bk + (size_t)step * trgsw_cplx;
-#pragma unroll
-        for (int j = 0; j < ROWS; j++) {
-            dst[j][0] = bk_i[(size_t)((j * 2 + 0) * R + wave) * 64 + lane];
-            dst[j][1] = bk_i[(size_t)((j * 2 + 1) * R + wave) * 64 + lane];
-        }
-    };
-#else
     // through a buffer resource: scalar offset of (step, row, component, wave) + one per-lane VGPR (see k_bootstrap_pair)
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(a.bk), 0, 0x7fffffff, 0x00020000);
@@ -138,7 +119,6 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             }
         }
     };
-#endif
     if (a.steps > 0) load_bk(0, bkv);
     // waves 0..3 = (component wave >> 1, parity wave & 1) of the I phase: their 15 twiddles stay in registers over the whole blind rotation
     // (the parity tables ride behind the table staged into LDS above)
@@ -175,7 +155,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
             const uint32_t* poly = accbuf + h * N;
             cplx* half = spec + (size_t)row * S::SROW + (k & 1) * (P / 2);
             cplx* xc = reinterpret_cast<cplx*>(smem + S::XBUF) + (size_t)k * Q4::XS;
-            __builtin_amdgcn_s_setprio(WG_HALF_PRIO);
+            __builtin_amdgcn_s_setprio(0);
             auto run = [&](auto odd) {
                 constexpr bool ODD = decltype(odd)::value;
                 double re[4], im[4];
@@ -187,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
                     re[m] = (double)decomp_digit((d0 + M) ^ M, BGBIT, jj);
                     im[m] = (double)decomp_digit((d1 + M) ^ M, BGBIT, jj);
                 }
-                sub256_forward<ODD, BOOT_TRIV>(re, im, qinv, xc, lane, [](int k) { if (WG_HALF_PRIO_AT && k == WG_HALF_PRIO_AT) __builtin_amdgcn_s_setprio(WG_HALF_PRIO_THEN); });
+                sub256_forward<ODD, BOOT_TRIV>(re, im, qinv, xc, lane, [](int k) { if (k == 2) __builtin_amdgcn_s_setprio(1); });
 #pragma unroll
                 for (int m = 0; m < 4; m++) half[m * 64 + lane] = make_double2(re[m], im[m]);
             };

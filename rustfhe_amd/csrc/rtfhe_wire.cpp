@@ -117,7 +117,7 @@ int rtfhe_tlwe_read(const char* path, int32_t* n, uint64_t* count, uint32_t* cts
 }
 
 
-// Twiddle tables as a file: pure file I/O here (the context-level rtfhe_twiddles_load / _write that compare and install live in rtfhe_api.hip).
+// Twiddle tables as a file: pure file I/O here (the context-level rtfhe_twiddles_load / _write that compare and install live in rtfhe_context.hip).
 // N = the ring degree; ifft_table / fft_table: 2N doubles each, the reference's memory layout.  Read verifies magic, degree and checksum.
 int rtfhe_twiddles_file_write(const char* path, int32_t N, const double* ifft_table, const double* fft_table) {
     if (!path || N < 16 || N > (1 << 20) || !ifft_table || !fft_table) return RTFHE_ERR_INVALID;

@@ -40,7 +40,7 @@ class Engine:
     def __init__(self, params=None, device=0, devices=None, reference_twiddles=True):
         """device: one GPU (rtfhe_ctx_create).  devices=[d0, d1, ...]: one context over several GPUs of the node
         (rtfhe_ctx_create_multi): keys are loaded once and replicated device-to-device, the host-buffer batch calls shard
-        contiguous gate ranges over them; *_dev and stage-level calls stay on devices[0].
+        contiguous gate ranges over them, the *_dev batch calls shard a batch resident on devices[0]; netlists and stage-level calls stay on devices[0].
         reference_twiddles: the context builds its twiddle tables with this host's libm; when that libm disagrees with the shipped
         tables of the reference build (a few entries may be an ulp apart between libms) the shipped tables are installed
         instead (rtfhe_twiddles_load) and self.twiddle_entries_replaced says how many entries differed.  False: this host's libm as it is."""
@@ -171,6 +171,19 @@ class Engine:
     def gate_batch_dev(self, op, d_in0, d_in1, d_out, count, stream=None):
         self._ck(self.L.rtfhe_gate_batch_dev(self.h, op, self._dev(d_in0), self._dev(d_in1), self._dev(d_out),
                                              count, C.c_void_p(stream) if stream else None))
+
+    def mux_batch_dev(self, d_c, d_in0, d_in1, d_out, count, stream=None):
+        self._ck(self.L.rtfhe_mux_batch_dev(self.h, self._dev(d_c), self._dev(d_in0), self._dev(d_in1), self._dev(d_out),
+                                            count, C.c_void_p(stream) if stream else None))
+
+    def bootstrap_batch_dev(self, d_tlwe, d_out, count, stream=None):
+        self._ck(self.L.rtfhe_bootstrap_batch_dev(self.h, self._dev(d_tlwe), self._dev(d_out), count, C.c_void_p(stream) if stream else None))
+
+    def memory_bytes(self, d=0):
+        """Device memory entry d of the context holds right now (keys in every layout built so far, tables, staging, scratch)."""
+        b = C.c_size_t()
+        self._ck(self.L.rtfhe_ctx_memory_bytes(self.h, d, C.byref(b)))
+        return b.value
 
     def circuit_wave_dev(self, d_ops, d_idx0, d_idx1, d_idx_out, d_wires, num_wires, count, stream=None):
         """One dependency wave of a netlist; wire indices / opcodes are validated on the device against num_wires

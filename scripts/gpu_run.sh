@@ -1,0 +1,47 @@
+#!/bin/bash
+# One parametrised GPU-box runner (round 5; replaces the per-experiment scripts/gpu_*.sh of rounds 2-4).
+#   usage (through gpurun):  bash scripts/gpu_run.sh <tag> <step> [<step> ...]      outputs under gpurun_out/<tag>/
+# steps:
+#   tests            the GPU suite (pytest -m gpu, one process)
+#   smoke            __graft_entry__.smoke()
+#   bench            python bench.py (default flags: headline + cpu baseline + secondary)
+#   bench20          python bench.py --steps 20 --warmup 5 (the driver's flags)
+#   config3          bench.py --workload config3 on one GPU
+#   ntt              bench.py --backend ntt-exact
+#   sweep[:N[:backend]]   scripts/sweep.py over the usual batch sizes (N = 1024 default, 2048; backend fft|ntt)
+#   circuit          scripts/bench_circuit.py (the adder netlists)
+#   profile          rocprofv3 kernel trace + PMC passes of the headline (scripts/profile_gpu.sh r05)
+#   profile2048      counters of the N = 2048 kernel (scripts/profile_n2048.sh eo)
+#   ab:<N>:<gates>:<rounds>:<lib>[,<lib>...]   same-process A/B of builds under build/ab/ ("shipped" = rustfhe_amd/librtfhe_hip.so)
+#   ubench:<name>    scripts/ubench/<name> (a prebuilt micro-benchmark binary)
+#   soak             scripts/soak.py
+#   py:<script>[:args,comma,separated]        any python script of scripts/
+# A step that fails or times out stops the run (no GPU step is started behind a dead one).
+set -o pipefail
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+run() { local name=$1; shift; echo "== $name: $*"; "$@"; local rc=$?; echo "== $name rc=$rc"; [ $rc -eq 0 ] || exit $rc; }
+for step in "$@"; do
+  IFS=: read -r kind a1 a2 a3 a4 <<< "$step"
+  case $kind in
+    tests)   run tests bash -c "timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=\$?; tail -3 $O/pytest_gpu.log; exit \$rc" ;;
+    smoke)   run smoke bash -c "timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; rc=\$?; tail -2 $O/smoke.log; exit \$rc" ;;
+    bench)   run bench bash -c "timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; rc=\$?; cut -c1-400 $O/bench.json; exit \$rc" ;;
+    bench20) run bench20 bash -c "timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2> $O/bench20.err; rc=\$?; cut -c1-400 $O/bench_steps20_warmup5.json; exit \$rc" ;;
+    config3) run config3 bash -c "timeout -k 10 300 python bench.py --workload config3 --steps 3 --warmup 1 ${a1:+--gpus-in-process $a1} > $O/bench_config3${a1:+_dev$a1}.json 2> $O/bench_config3.err; rc=\$?; cut -c1-300 $O/bench_config3${a1:+_dev$a1}.json; exit \$rc" ;;
+    ntt)     run ntt bash -c "timeout -k 10 300 python bench.py --backend ntt-exact --no-cpu-baseline > $O/bench_ntt_exact.json 2> $O/bench_ntt.err; rc=\$?; cut -c1-300 $O/bench_ntt_exact.json; exit \$rc" ;;
+    sweep)   n=${a1:-1024}; be=${a2:-fft}; sizes=1,256,512,768,1024,1280,1536,2048,4096,8192; [ $n = 2048 ] && sizes=1,256,512,768,1024,2048; [ $be = ntt ] && sizes=1,512,1024
+             run sweep env RTFHE_N=$n RTFHE_BACKEND=$be RTFHE_SKIP_STAGES=1 bash -c "timeout -k 10 300 python scripts/sweep.py $sizes > $O/sweep_N${n}_$be.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/sweep_N${n}_$be.log; exit \$rc" ;;
+    circuit) run circuit bash -c "timeout -k 10 300 python scripts/bench_circuit.py > $O/bench_circuit.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/bench_circuit.log | tail -12; exit \$rc" ;;
+    profile) run profile bash -c "bash scripts/profile_gpu.sh r05 > $O/profile.log 2>&1; rc=\$?; tail -3 $O/profile.log; cp -r gpurun_out/profiles_r05 $O/ 2>/dev/null; exit \$rc" ;;
+    profile2048) run profile2048 bash -c "bash scripts/profile_n2048.sh ${a1:-eo} > $O/profile_n2048.log 2>&1; rc=\$?; tail -3 $O/profile_n2048.log; cp gpurun_out/profiles_n2048/pmc_n2048_${a1:-eo}.json $O/ 2>/dev/null; exit \$rc" ;;
+    ab)      libs=$(echo "$a4" | tr ',' ' ' | sed -E 's#(^| )shipped#\1rustfhe_amd/librtfhe_hip.so#g; s#(^| )([A-Za-z0-9_]+)( |$)#\1build/ab/\2.so\3#g; s#(^| )([A-Za-z0-9_]+)( |$)#\1build/ab/\2.so\3#g')
+             run "ab N=$a1 gates=$a2" env RTFHE_N=$a1 bash -c "timeout -k 10 400 python scripts/ab_libs.py $a2 $a3 $libs 2>&1 | grep -v amdgpu.ids | tee -a $O/ab_N${a1}_g${a2}.log" ;;
+    ubench)  run "ubench $a1" bash -c "timeout -k 10 300 scripts/ubench/$a1 > $O/ubench_$a1.log 2>&1; rc=\$?; cat $O/ubench_$a1.log; exit \$rc" ;;
+    soak)    run soak bash -c "timeout -k 10 600 python scripts/soak.py > $O/soak.log 2>&1; rc=\$?; tail -5 $O/soak.log; exit \$rc" ;;
+    py)      args=$(echo "$a2" | tr ',' ' '); run "py $a1" bash -c "timeout -k 10 500 python scripts/$a1 $args > $O/$(basename $a1 .py).log 2>&1; rc=\$?; grep -v amdgpu.ids $O/$(basename $a1 .py).log | tail -40; exit \$rc" ;;
+    *) echo "unknown step $step"; exit 64 ;;
+  esac
+done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compiler-reported resources of every kernel in librtfhe_hip.so (hipcc -Rpass-analysis=kernel-resource-usage, the same
 flags as the build) -> profiles/<tag>/kernel_resources.json.  Runs on CPU (cross-compile).  Dynamic LDS is what the host
-passes at launch (formulas of rtfhe_api.hip restated below for the default parameter set n = 635).
+passes at launch (formulas of rtfhe_dispatch_fft.hip restated below for the default parameter set n = 635).
 
     python scripts/kernel_resources.py r02
 """
@@ -18,10 +18,7 @@ from rustfhe_amd import build as b  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 with tempfile.TemporaryDirectory() as td:
-    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + list(getattr(b, "EXTRA", [])) + \
-          ["--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"),
-           "-o", os.path.join(td, "api.o")]
-    err = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    _, err = b.device_asm(td)
     demangle = lambda s: subprocess.run(["c++filt", s], capture_output=True, text=True).stdout.strip()
 
 kernels, cur = {}, None

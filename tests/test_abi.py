@@ -40,7 +40,7 @@ int main(void) {
     if (rc == 0) { if (rtfhe_ctx_device_count(ctx) != 1) return 3; rtfhe_ctx_destroy(ctx); }
     /* the multi-device form: same refusal without a GPU, argument checks first */
     int ids[2] = {0, 0}; rtfhe_ctx *m = 0;
-    if (rtfhe_ctx_create_multi(&p, ids, 2, &m) != RTFHE_ERR_INVALID || m) return 4;      /* duplicate device */
+    if (rtfhe_ctx_create_multi(&p, ids, 65, &m) != RTFHE_ERR_INVALID || m) return 4;     /* more entries than a node has places */
     if (rtfhe_ctx_create_multi(&p, ids, 0, &m) != RTFHE_ERR_INVALID) return 5;
     int rcm = rtfhe_ctx_create_multi(&p, ids, 1, &m);
     if (rtfhe_device_count() == 0 ? (rcm != RTFHE_ERR_NO_DEVICE || m) : (rcm != 0 || rtfhe_ctx_device_count(m) != 1)) return 6;

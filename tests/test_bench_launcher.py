@@ -75,23 +75,29 @@ def test_dp_opcount_formula():
     assert ops["reference"] == 3808 and ops["cvt_trunc"] == 128
     assert ops["total"] == 3808 - 8 * 6 - 16 and ops["add_mul"] == 3680 - 8 * 6 - 16      # unit-twiddle butterflies, first fold row
     assert bench.dp_wave_instr_per_cmux(2048, 3)["transform"] == 800
-    assert bench.dp_wave_instr_per_cmux(2048, 3)["reference"] == 8256 and bench.dp_wave_instr_per_cmux(2048, 3, "top_bit")["total"] == 8256 - 96
-    assert bench.dp_wave_instr_per_cmux(2048, 3, "parity")["total"] == 8256 - 8 * 18 == bench.dp_wave_instr_per_cmux(2048, 3)["total"]
+    assert bench.dp_wave_instr_per_cmux(2048, 3)["reference"] == 8256
+    assert bench.dp_wave_instr_per_cmux(2048, 3)["total"] == 8256 - 8 * 18
     assert abs(bench.FP64_VALU_PEAK - 39.3216e12) < 1e6
     assert bench.ALG_BYTES_PER_GATE == 78061008
 
 
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """device assembly of every unit of the library, compiled once for the ISA checks below (hipcc -S --cuda-device-only, the build's flags)"""
+    import pathlib
+    from rustfhe_amd import build as b
+    path, _ = b.device_asm(str(tmp_path_factory.mktemp("isa")))
+    return pathlib.Path(path)
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-def test_dp_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
+def test_dp_opcount_matches_the_isa_of_the_built_kernel(device_asm):
     """The count behind roofline.achieved is not a literal: the formula must agree with the v_add/v_mul_f64 (+ cvt/trunc)
     instructions hipcc emits for k_bootstrap_pair's step loop.  The loop body holds slot P (side 0 only), slot Q (both)
     and slot R (side 1 only): a wave executes all of it but one three-row slot, so static = per-wave + 3 MAC rows."""
     import bench
     from rustfhe_amd import build as b
-    asm = tmp_path / "api.s"
-    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + \
-          ["--cuda-device-only", "-S", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"), "-o", str(asm)]
-    subprocess.check_call(cmd)
+    asm = device_asm
     text = asm.read_text()
     m = re.search(r"\n(_ZN5rtfhe16k_bootstrap_pair\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S)
     assert m, "k_bootstrap_pair not found in the device assembly"
@@ -113,17 +119,14 @@ def test_dp_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-def test_n2048_parity_split_kernel_executes_the_reference_operation_list(tmp_path):
+def test_n2048_parity_split_kernel_executes_the_reference_operation_list(device_asm):
     """k_bootstrap_eo holds its step loop twice (one copy per parity, each with its polynomial loop and its component loop not unrolled): the
     FP64-rate instructions of the two copies together are what the two waves of a gate execute per (polynomial + component) -- the reference's
     operation list for N = 2048 (bench.dp_wave_instr_per_cmux: 8,256 per CMUX = 2 x 4,128) minus the unit-twiddle butterflies of the
     even-point network (3 per transform x 6 instructions: one in the halfnn = 8 stage, two in the halfnn = 4 stage), and no v_fma_f64."""
     import bench
     from rustfhe_amd import build as b
-    asm = tmp_path / "api.s"
-    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + \
-          ["--cuda-device-only", "-S", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"), "-o", str(asm)]
-    subprocess.check_call(cmd)
+    asm = device_asm
     m = re.search(r"\n(_ZN5rtfhe14k_bootstrap_eoILi3ELi6ELi8ELi2ELi3ELi4E\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm.read_text(), re.S)
     assert m, "k_bootstrap_eo not found in the device assembly"
     f64 = len(re.findall(r"^\s*v_(?:add|mul|cvt_f64_i32|trunc)_f64|^\s*v_cvt_f64_i32|^\s*v_trunc_f64", m.group(2), re.M))
@@ -131,7 +134,7 @@ def test_n2048_parity_split_kernel_executes_the_reference_operation_list(tmp_pat
     ref = bench.dp_wave_instr_per_cmux(2048, 3)["reference"]
     # static = (one polynomial + one component) per parity = half a CMUX step per parity; the even parity saves 18 per transform, 4 transforms in it
     assert f64 == ref // 2 - 4 * 18, (f64, ref)
-    assert 2 * f64 == bench.dp_wave_instr_per_cmux(2048, 3, "parity")["total"]          # the count bench.py prices secondary.config5 with
+    assert 2 * f64 == bench.dp_wave_instr_per_cmux(2048, 3)["total"]          # the count bench.py prices secondary.config5 with
 
 
 def test_ntt_opcount_formula():
@@ -143,15 +146,12 @@ def test_ntt_opcount_formula():
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-def test_ntt_opcount_matches_the_isa_of_the_built_kernel(tmp_path):
+def test_ntt_opcount_matches_the_isa_of_the_built_kernel(device_asm):
     """k_bootstrap_ntt_pair's step loop holds the row loop's body once (not unrolled) and the step's tail: the static count of
     FP64-rate instructions must be the formula's one-row count."""
     import bench
     from rustfhe_amd import build as b
-    asm = tmp_path / "api.s"
-    cmd = ["/opt/rocm/bin/hipcc"] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC", "-pthread")] + \
-          ["--cuda-device-only", "-S", "-x", "hip", os.path.join(b.CSRC, "rtfhe_api.hip"), "-o", str(asm)]
-    subprocess.check_call(cmd)
+    asm = device_asm
     text = asm.read_text()
     m = re.search(r"\n(_ZN5rtfhe20k_bootstrap_ntt_pairILi3ELi6ELi8ELi2ELi3ELi4E\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S)
     assert m, "k_bootstrap_ntt_pair not found in the device assembly"

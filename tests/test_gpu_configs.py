@@ -308,20 +308,18 @@ def test_key_file_feeds_an_engine(tmp_path, params, keys, gold_gate):
     e.close()
 
 
-@pytest.mark.parametrize("other", ["one_wave_per_gate", "top_bit_split", "parity_split"])
-def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch, other):
+def test_config5_both_kernel_shapes_agree(setup2048, orc, monkeypatch):
     """N = 2048: the default dispatch (transforms split over two waves by the parity of the point index: k_bootstrap_eo4, four waves per gate, for
     up to two gates per CU -- the ragged 37-gate batch, the blind-rotate prefixes and the 257-gate shape below run on it -- and k_bootstrap_eo, two
-    waves per gate, beyond) against the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4) and against each two-wave split forced for every shape
-    (RTFHE_N2048_KERNEL=eo: the parity split, =halves: the split by the top index bit) -- the same arithmetic: identical words for a ragged batch,
-    for blind-rotate prefixes (both compared with the oracle above) and for every launch shape."""
+    waves per gate, beyond) against the one-wave-per-gate kernel (RTFHE_FORCE_WAVES=4, k_bootstrap<11>: a whole transform in one wave, no
+    split at all) -- the same arithmetic: identical words for a ragged batch, for blind-rotate prefixes (both compared with the oracle above)
+    and for every launch shape."""
     import rustfhe_amd as R
     P, K, e = setup2048
     rng = np.random.default_rng(2048)
     b0, b1 = rng.integers(0, 2, 37), rng.integers(0, 2, 37)
     c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
-    knob, val = {"one_wave_per_gate": ("RTFHE_FORCE_WAVES", "4"), "top_bit_split": ("RTFHE_N2048_KERNEL", "halves"),
-                 "parity_split": ("RTFHE_N2048_KERNEL", "eo")}[other]
+    knob, val = "RTFHE_FORCE_WAVES", "4"
     monkeypatch.setenv(knob, val)
     one = R.Engine(R.Params(N=2048), 0)
     monkeypatch.delenv(knob)

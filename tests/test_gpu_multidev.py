@@ -1,18 +1,17 @@
-"""The multi-device context (rtfhe_ctx_create_multi) with n_dev > 1 on a ONE-GPU box: the test-only switch
-RTFHE_TEST_ALLOW_DUP_DEVICES=1 lets device 0 appear several times, so that everything behind the call runs -- one full context per
-entry, keys transformed once and copied device-to-device (hipMemcpyPeer), one host thread + stream per entry, contiguous shard
-ranges [count d / D, count (d+1) / D), error aggregation -- and every result is compared word for word with the single-device
-engine.  (A node with several GPUs runs exactly this code with distinct ids; that run is the driver's.)"""
+"""The multi-device context (rtfhe_ctx_create_multi) with n_dev > 1 on a ONE-GPU box: a device may be named more than once (every entry is
+a full context of its own), so device 0 appears several times and everything behind the call runs -- one full context per entry, keys
+transformed once and copied device-to-device (hipMemcpyPeer), contiguous shard ranges [count d / D, count (d+1) / D), one host thread +
+stream per entry for host batches, peer pulls / pushes and cross-stream events for batches resident on the primary, error aggregation --
+and every result is compared word for word with the single-device engine.  (A node with several GPUs runs exactly this code with
+distinct ids; that run is the driver's.)"""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def _pair(R, p, bk, ksk, devices, monkeypatch, bk_fft=None):
-    monkeypatch.setenv("RTFHE_TEST_ALLOW_DUP_DEVICES", "1")
+def _pair(R, p, bk, ksk, devices, bk_fft=None):
     m = R.Engine(p, devices=devices)
-    monkeypatch.delenv("RTFHE_TEST_ALLOW_DUP_DEVICES")
     s = R.Engine(p, 0)
     for e in (m, s):
         e.load_bk_torus(bk)
@@ -20,17 +19,11 @@ def _pair(R, p, bk, ksk, devices, monkeypatch, bk_fft=None):
     return m, s
 
 
-def test_duplicate_ids_are_refused_without_the_switch(params):
-    import rustfhe_amd as R
-    with pytest.raises(R.RtfheError):
-        R.Engine(R.Params(), devices=[0, 0])
-
-
 @pytest.mark.parametrize("n_dev", [2, 3])
-def test_sharded_host_batches_equal_single_device_n1024(params, keys, gold_gate, monkeypatch, n_dev):
+def test_sharded_host_batches_equal_single_device_n1024(params, keys, gold_gate, n_dev):
     import rustfhe_amd as R
     p = R.Params()
-    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0] * n_dev, monkeypatch)
+    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0] * n_dev)
     try:
         assert m.device_count() == n_dev and s.device_count() == 1
         ops, in0, in1 = gold_gate["ops"], gold_gate["in0"], gold_gate["in1"]
@@ -66,13 +59,13 @@ def test_sharded_host_batches_equal_single_device_n1024(params, keys, gold_gate,
         m.close(); s.close()
 
 
-def test_sharded_host_batches_equal_single_device_n2048(monkeypatch):
-    """N = 2048 (BASELINE config 5's ring) with a small TLWE dimension so that key generation stays short: the halves-layout key
-    and the NTT tables are rebuilt on every peer (build_halves_bk, ntt_prepare)."""
+def test_sharded_host_batches_equal_single_device_n2048():
+    """N = 2048 (BASELINE config 5's ring) with a small TLWE dimension so that key generation stays short: the parity-split key
+    layout and the NTT tables are rebuilt on every peer (ntt_prepare)."""
     import rustfhe_amd as R
     p = R.Params(N=2048, n=24)
     key0, key1, bk, ksk = R.keygen(p, 2048)
-    m, s = _pair(R, p, bk, ksk, [0, 0], monkeypatch)
+    m, s = _pair(R, p, bk, ksk, [0, 0])
     try:
         rng = np.random.default_rng(5)
         b0, b1 = rng.integers(0, 2, 9).astype(np.uint8), rng.integers(0, 2, 9).astype(np.uint8)
@@ -85,6 +78,89 @@ def test_sharded_host_batches_equal_single_device_n2048(monkeypatch):
         assert np.array_equal(m.blind_rotate_batch(c0[:3], 4), s.blind_rotate_batch(c0[:3], 4))
         m.set_backend(R._ffi.BACKEND_NTT_EXACT); s.set_backend(R._ffi.BACKEND_NTT_EXACT)
         assert np.array_equal(m.gate_batch(R.OR, c0[:3], c1[:3]), s.gate_batch(R.OR, c0[:3], c1[:3]))
+    finally:
+        m.close(); s.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_a_batch_resident_on_the_primary_is_sharded_behind_the_c_abi(params, keys, n_dev):
+    """rtfhe_gate_batch_dev / rtfhe_mux_batch_dev / rtfhe_bootstrap_batch_dev on a multi-device context: the batch lives on the primary; the
+    other entries pull their ranges (hipMemcpyPeerAsync on their own streams), bootstrap them and push the outputs back while the primary
+    computes its own range; the caller's stream waits for their events.  Word for word the single-device call at 8,192 and 65,536 gates
+    (BASELINE config 3's per-GPU and whole-node counts), at ragged counts, with entries that get no gate, back to back on one stream
+    without a host synchronisation in between, and with the inputs overwritten right behind the call (stream order must hold)."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0] * n_dev)
+    try:
+        G = 65536
+        rng = np.random.default_rng(77 + n_dev)
+        base = 1031                                                   # distinct ciphertexts, tiled: every shard boundary falls between different rows
+        b0, b1 = rng.integers(0, 2, base), rng.integers(0, 2, base)
+        c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+        reps = (G + base - 1) // base
+        d0 = torch.from_numpy(np.tile(c0, (reps, 1))[:G].view(np.int32)).cuda()
+        d1 = torch.from_numpy(np.tile(c1, (reps, 1))[:G].view(np.int32)).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        ref = torch.empty_like(d0)
+        s.gate_batch_dev(R.NAND, d0, d1, ref, G, st); s.sync(st)
+        assert keys.decrypt_bits(ref[:base].cpu().numpy().view(np.uint32)) == list(1 - (b0 & b1))
+        for count in (G, 8192, 8191, 1030, n_dev + 1, n_dev, n_dev - 1, 1, 0):
+            out = torch.full_like(d0, -1)
+            m.gate_batch_dev(R.NAND, d0, d1, out, count, st); m.sync(st)
+            assert torch.equal(out[:count], ref[:count]), count
+            assert bool((out[count:] == -1).all()), "rows beyond the batch were written"
+        # unary gate and raw bootstrap (no second input), MUX (three inputs, two intermediate batches per entry)
+        k = 3000
+        for op in (R.NOT, R.COPY):
+            a, b = torch.empty_like(d0[:k]), torch.empty_like(d0[:k])
+            s.gate_batch_dev(op, d0, None, a, k, st); m.gate_batch_dev(op, d0, None, b, k, st); m.sync(st)
+            assert torch.equal(a, b), op
+        a, b = torch.empty_like(d0[:k]), torch.empty_like(d0[:k])
+        s.bootstrap_batch_dev(d0, a, k, st); m.bootstrap_batch_dev(d0, b, k, st); m.sync(st)
+        assert torch.equal(a, b)
+        sel = d1[5:5 + k].contiguous()
+        s.mux_batch_dev(sel, d0, d1, a, k, st); m.mux_batch_dev(sel, d0, d1, b, k, st); m.sync(st)
+        assert torch.equal(a, b)
+        assert np.array_equal(a[:7].cpu().numpy().view(np.uint32), s.mux_batch(sel[:7].cpu().numpy().view(np.uint32), c0[:7], c1[:7]))
+        # two batches back to back, then the inputs clobbered on the same stream: what the peers pull must be what stream order promises
+        x0, x1 = d0[:4096].clone(), d1[:4096].clone()
+        o1, o2 = torch.empty_like(x0), torch.empty_like(x0)
+        m.gate_batch_dev(R.NAND, x0, x1, o1, 4096, st)
+        m.gate_batch_dev(R.XOR, o1, x1, o2, 4096, st)                 # reads the first batch's outputs, gathered from every entry
+        x0.zero_(); x1.zero_()                                        # enqueued behind both batches
+        m.sync(st)
+        r1, r2 = torch.empty_like(o1), torch.empty_like(o1)
+        s.gate_batch_dev(R.NAND, d0[:4096], d1[:4096], r1, 4096, st); s.gate_batch_dev(R.XOR, r1, d1[:4096], r2, 4096, st); s.sync(st)
+        assert torch.equal(o1, r1) and torch.equal(o2, r2)
+        # footprint: every entry holds its own key replica; the primary's staging is not used by a device-resident batch
+        assert m.memory_bytes(1) > 0 and m.memory_bytes(0) > 0
+        with pytest.raises(R.RtfheError):
+            m.memory_bytes(n_dev)
+    finally:
+        m.close(); s.close()
+
+
+def test_a_device_resident_batch_inside_a_callers_capture_stays_on_the_primary(params, keys):
+    """Inside a stream capture the staging buffers of the other entries are not the capture's to bake in: the whole batch runs on the primary
+    (fused kernel, canonical key layout), and the captured graph replays to the same words."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0, 0])
+    try:
+        b0, b1 = [0, 1, 1, 0, 1], [1, 1, 0, 0, 1]
+        d0 = torch.from_numpy(keys.encrypt_bits(b0).view(np.int32)).cuda()
+        d1 = torch.from_numpy(keys.encrypt_bits(b1).view(np.int32)).cuda()
+        ref, out = torch.empty_like(d0), torch.zeros_like(d0)
+        s.gate_batch_dev(R.AND, d0, d1, ref, 5); s.sync()
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            m.gate_batch_dev(R.AND, d0, d1, out, 5, torch.cuda.current_stream().cuda_stream)
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(out, ref)
     finally:
         m.close(); s.close()
 

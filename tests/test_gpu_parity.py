@@ -34,17 +34,24 @@ def test_twiddles_match_reference_tables(engine, orc, params):
     assert engine.twiddles()[0].tobytes() == a.tobytes()
 
 
-def test_a_host_libm_that_disagrees_is_overridden_by_the_shipped_reference_tables(keys, gold_gate, monkeypatch, tmp_path):
+def test_a_host_libm_that_disagrees_is_overridden_by_the_shipped_reference_tables(keys, gold_gate, tmp_path):
     """the twiddle tables are libm outputs, two libms may differ by an ulp in a few entries, and one differing entry changes
-    torus words.  RTFHE_TEST_PERTURB_TWIDDLE moves ONE entry of the table the context builds by one ulp (a stand-in for such a host).
-    Left alone, that context no longer reproduces the reference build's tables (nor, in general, its spectra); the default engine notices the
-    disagreement with rustfhe_amd/assets/twiddles_N1024.bin, installs the shipped tables and reproduces the golden gates word for word."""
+    torus words.  A host whose libm disagrees is stood in for through the public boundary: ONE entry of the tables a context has built is
+    moved by one ulp (rtfhe_get_twiddles / rtfhe_set_twiddles -- no hook inside the library).  Left alone, that context no longer reproduces
+    the reference build's tables (nor, in general, its spectra); rtfhe_twiddles_load -- what the default engine runs at construction --
+    notices the disagreement with rustfhe_amd/assets/twiddles_N1024.bin, installs the shipped tables and the golden gates come out word for word."""
     import rustfhe_amd as R
     g = golden("fft_N1024.npz")
-    monkeypatch.setenv("RTFHE_TEST_PERTURB_TWIDDLE", "37")
     p = R.Params()
-    raw = R.Engine(p, 0, reference_twiddles=False)
-    fixed = R.Engine(p, 0)
+
+    def perturbed():
+        e = R.Engine(p, 0, reference_twiddles=False)
+        a, b = e.twiddles()
+        a[8 * 9 + 1] = np.nextafter(a[8 * 9 + 1], 2.0)            # a cosine of the twist block: every forward transform reads it
+        e.set_twiddles(a, b)
+        return e
+    raw, fixed = perturbed(), perturbed()
+    fixed.twiddle_entries_replaced = fixed.twiddles_load(R.engine.reference_twiddle_file(1024))
     try:
         ra, rb = raw.twiddles()
         assert int((ra.view(np.uint64) != g["ifft_table"].view(np.uint64)).sum()) == 1 and rb.tobytes() == g["fft_table"].tobytes()
