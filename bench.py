@@ -388,6 +388,8 @@ def supervise(child_cmd, env=None):
         return rc if rc > 0 else 1
     pending = last.pop("provisional", None)
     if rc != 0:
+        sys.stderr.write("bench.py: THE MEASURING PROCESS DIED (rc %s, %s) after the headline was complete; legs not completed: %s -- the line "
+                         "below carries side_leg_crash, the exit code stays 0 so that the headline is not lost\n" % (rc, _signal_name(rc), pending))
         last["side_leg_crash"] = {"rc": rc, "signal": _signal_name(rc), "legs_not_completed": pending,
                                   "note": "the measuring process died AFTER the headline above was complete; the value, roofline and every leg "
                                           "present in this line were measured before that"}
@@ -482,6 +484,54 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
             run.close()
         sec["config4_adder_8bit_one_replica"] = adders
     guard("config4_adder_8bit_one_replica", _config4_adder_8bit_one_replica)
+    # -- ... and its throughput form: 1024 replicas of each netlist side by side (a wave of the netlist = 1024 x its gates of that level).
+    #    "config 4 as named" (BASELINE configs[3]) is the ripple-carry NAND-only netlist: 72 gates, 20 levels.
+    def _config4_adder_8bit_1024_replicas():
+        reps, adders = 1024, {}
+        for name, net in (("ripple_carry_nand_only", ripple_carry_adder(8, True)), ("ripple_carry_xor_and_or", ripple_carry_adder(8, False)),
+                          ("parallel_prefix_nand_only", prefix_adder(8, True)), ("parallel_prefix_xor_and_or", prefix_adder(8, False))):
+            A, B = rng.integers(0, 256, reps), rng.integers(0, 256, reps)
+            bits = np.array([[(a >> i) & 1 for i in range(8)] + [(b >> i) & 1 for i in range(8)] for a, b in zip(A, B)], np.uint8)
+            run = CircuitRunner(eng, net, reps)
+            run.set_inputs(R.encrypt_bits(params, key0, bits.reshape(-1), 33).reshape(reps, 16, params.n + 1))
+            run.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run.run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            dec = R.decrypt_bits(params, key0, run.outputs().reshape(-1, params.n + 1)).reshape(reps, 9)
+            d = net.describe()
+            adders[name] = {"ms_per_1024_additions": round(dt * 1e3, 2), "additions_per_s": round(reps / dt, 1), "gates_per_s": round(reps * d["gates"] / dt, 1),
+                            "gates": d["gates"], "levels": d["depth"], "kernel": "k_bootstrap_pair",
+                            "roofline_frac_fp64": fp64_frac(ops, params.n, reps * d["gates"], dt),
+                            "ok": bool(np.array_equal((dec * (1 << np.arange(9))).sum(axis=1), A + B))}
+            run.close()
+        sec["config4_adder_8bit_1024_replicas"] = {"config4_as_named": "ripple_carry_nand_only", **adders}
+    guard("config4_adder_8bit_1024_replicas", _config4_adder_8bit_1024_replicas)
+    # -- BASELINE configs[2] behind the C ABI: a batch resident on one device sharded by a multi-device CONTEXT (rtfhe_gate_batch_dev on
+    #    rtfhe_ctx_create_multi; no Python, no process per GPU in the data path).  On this one-GPU run the context names the GPU twice: the
+    #    number prices the sharding machinery (peer copies, events, two streams sharing the card), not a second GPU.
+    def _config3_c_abi_two_contexts_one_gpu():
+        G3 = 8192
+        bb = rng.integers(0, 2, (2, G3)).astype(np.uint8)
+        f0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 23).view(np.int32)).to(gpu)
+        f1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 24).view(np.int32)).to(gpu)
+        fo = torch.empty_like(f0)
+        m = R.Engine(params, devices=[gpu.index, gpu.index])
+        try:
+            m.load_bk_torus(bk)
+            m.load_ksk(ksk)
+            m.gate_batch_dev(R.NAND, f0, f1, fo, G3, stream); m.sync(stream)
+            t0 = time.perf_counter()
+            m.gate_batch_dev(R.NAND, f0, f1, fo, G3, stream); m.sync(stream)
+            wall = time.perf_counter() - t0
+            okm = bool(np.array_equal(R.decrypt_bits(params, key0, fo.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+            sec["config3_c_abi_two_contexts_one_gpu"] = {"gates_per_s": round(G3 / wall, 1), "ms_per_step": round(wall * 1e3, 3), "entries": 2,
+                                                        "device_bytes_per_entry": [m.memory_bytes(0), m.memory_bytes(1)], "ok": okm}
+        finally:
+            m.close()
+    guard("config3_c_abi_two_contexts_one_gpu", _config3_c_abi_two_contexts_one_gpu)
     # -- the NTT backend north_star names, 1024 gates (exact-integer arithmetic; decrypt-level parity with the reference)
     def _ntt_exact_1024_gates():
         G = 1024
@@ -726,9 +776,9 @@ def run_rank(args):
         d_in0 = torch.from_numpy(in0.view(np.int32)).to(gpu)
         d_in1 = torch.from_numpy(in1.view(np.int32)).to(gpu)
         d_out = torch.empty_like(d_in0)
-        # Clock settle (set-up, like the key load; never timed): the first launches after idle run at a lower clock (rocprofv3 of round 3:
-        # 8.0 -> 6.4 ms over five launches).  Untimed launches until three in a row agree within 1 %, at most SETTLE_MAX; the W warm-up steps
-        # the caller asked for follow, then the K timed ones.  The count is reported in config.clock_settle_launches; --settle-max 0 turns it off.
+        # Optional clock settle (--settle-max N > 0; default OFF: the driver's contract is exactly W untimed warm-up steps): the first launches
+        # after idle run at a lower clock (rocprofv3 of round 3: 8.0 -> 6.4 ms over five launches).  Untimed launches until three in a row agree
+        # within 1 %, at most N; then the W warm-up steps, then the K timed ones.  The count is reported in config.clock_settle_launches.
         settle, recent = 0, []
         while settle < args.settle_max:
             eng.timer_begin(stream)
@@ -888,7 +938,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs / NTT backend measured after the headline")
     ap.add_argument("--cpu-gates-per-thread", type=int, default=24, help="least number of gates every thread of the all-core CPU baseline runs")
-    ap.add_argument("--settle-max", type=int, default=16, help="most untimed clock-settle launches before the warm-up steps (0: none)")
+    ap.add_argument("--settle-max", type=int, default=0, help="untimed clock-settle launches BEFORE the caller's warm-up steps, at most this many "
+                    "(default 0: exactly --warmup untimed steps, the driver's contract; > 0: launches until three in a row agree within 1 %%)")
     ap.add_argument("--cpu-baseline-child", metavar="DIR", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:

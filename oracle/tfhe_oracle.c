@@ -642,10 +642,29 @@ typedef struct {
     double **rep_bk; uint32_t **rep_ksk;        /* per node, filled by the node's leader */
     pthread_barrier_t *filled, *ready;
     int *fail;
+    struct start_gate *gate;
 } numa_job;
+
+/* Every worker waits here until ALL threads exist: the barriers below are sized for nthreads, so a worker that ran ahead into one while a
+ * later pthread_create failed (thread / process limits of the host) would wait for ever.  state: 0 = wait, 1 = go, 2 = give up. */
+typedef struct start_gate { pthread_mutex_t m; pthread_cond_t c; int state; } start_gate;
+static int gate_wait(start_gate *g) {
+    pthread_mutex_lock(&g->m);
+    while (g->state == 0) pthread_cond_wait(&g->c, &g->m);
+    const int st = g->state;
+    pthread_mutex_unlock(&g->m);
+    return st;
+}
+static void gate_open(start_gate *g, int state) {
+    pthread_mutex_lock(&g->m);
+    g->state = state;
+    pthread_cond_broadcast(&g->c);
+    pthread_mutex_unlock(&g->m);
+}
 
 static void *numa_worker(void *arg) {
     numa_job *j = (numa_job *)arg;
+    if (gate_wait(j->gate) != 1) return NULL;
     if (j->cpu >= 0) {
         cpu_set_t set;
         CPU_ZERO(&set);
@@ -694,9 +713,16 @@ double orc_gate_batch_mt_numa(const orc_params *p, int backend, int op, const do
     int *seen = (int *)calloc((size_t)nnodes, sizeof(int));
     int fail = 0;
     pthread_barrier_t filled, ready;
-    pthread_barrier_init(&filled, NULL, (unsigned)nthreads);
-    pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1u);
+    start_gate gate = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0};
+    if (!th || !jobs || !rep_bk || !rep_ksk || !seen) { free(th); free(jobs); free(rep_bk); free(rep_ksk); free(seen); return -1.0; }
+    if (pthread_barrier_init(&filled, NULL, (unsigned)nthreads) != 0) { free(th); free(jobs); free(rep_bk); free(rep_ksk); free(seen); return -1.0; }
+    if (pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1u) != 0) {
+        pthread_barrier_destroy(&filled);
+        free(th); free(jobs); free(rep_bk); free(rep_ksk); free(seen);
+        return -1.0;
+    }
     struct timespec t0, t1;
+    int created = 0;
     for (int t = 0; t < nthreads; t++) {
         int node = node_of_thread ? node_of_thread[t] : 0;
         if (node < 0 || node >= nnodes) node = 0;
@@ -704,9 +730,19 @@ double orc_gate_batch_mt_numa(const orc_params *p, int backend, int op, const do
         seen[node] = 1;
         jobs[t] = (numa_job){p, backend, op, bk_f, bk_doubles, ksk, ksk_words, in0, in1, out, in_count,
                              count * (size_t)t / (size_t)nthreads, count * (size_t)(t + 1) / (size_t)nthreads,
-                             cpus ? cpus[t] : -1, node, leader, rep_bk, rep_ksk, &filled, &ready, &fail};
-        pthread_create(&th[t], NULL, numa_worker, &jobs[t]);
+                             cpus ? cpus[t] : -1, node, leader, rep_bk, rep_ksk, &filled, &ready, &fail, &gate};
+        if (pthread_create(&th[t], NULL, numa_worker, &jobs[t]) != 0) break;
+        created++;
     }
+    if (created < nthreads) {              /* the threads that exist never reach a barrier: release them, join them, report failure */
+        gate_open(&gate, 2);
+        for (int t = 0; t < created; t++) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&filled);
+        pthread_barrier_destroy(&ready);
+        free(rep_bk); free(rep_ksk); free(seen); free(th); free(jobs);
+        return -1.0;
+    }
+    gate_open(&gate, 1);
     pthread_barrier_wait(&ready);
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);

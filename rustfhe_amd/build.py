@@ -37,14 +37,14 @@ def stale(lib=LIB):
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def compile_all(out_lib, extra=(), obj_dir=OBJ, verbose=False, jobs=None):
-    """Compiles every unit with CFLAGS + extra into obj_dir and links out_lib (atomically: temporary name, then rename)."""
+def compile_all(out_lib, extra=(), obj_dir=OBJ, verbose=False, jobs=None, csrc=CSRC):
+    """Compiles every unit of `csrc` with CFLAGS + extra into obj_dir and links out_lib (atomically: temporary name, then rename)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(obj_dir, exist_ok=True)
 
     def one(src):
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + CFLAGS + list(extra) + ["-c", "-x", "hip", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + CFLAGS + list(extra) + ["-I", os.path.join(HERE, "..", "include"), "-c", "-x", "hip", os.path.join(csrc, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

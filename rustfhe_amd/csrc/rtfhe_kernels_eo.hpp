@@ -23,7 +23,13 @@
 // instructions of a wave execute in order) -- so there is no "buffer free" synchronisation: ONE arrival / wait per trade, 3 per polynomial + 1 per
 // inverse = 8 per step.  Same arithmetic DAG as the reference, every product and sum rounded on its own (-ffp-contract=off): bit-identical to
 // k_bootstrap<11> (tests/test_gpu_configs.py::test_config5_*).
-// LDS: the per-parity stage tables of passes 1-3 (16 KiB forward, 2 KiB inverse); twist / untwist / inverse pass-1 tables in global memory.
+// LDS: the per-parity stage tables of passes 1-3 (16 KiB forward, 2 KiB inverse); twist / untwist / inverse pass-1 tables in global memory
+// (a vector-memory read costs the SIMD's issue less than an LDS read does, and LDS is full: profiles/r05/vmem_issue.log).
+// The accumulator lives in LDS as PARITY PLANES: coefficient c of a polynomial at word 1024 (c & 1) + (c >> 1) of its 8 KiB.  Wave H reads and
+// updates the coefficients of parity H only (c = 2 (lane + 64 k) + H), and the rotated coefficients it gathers all have the parity of H - r
+// (wave-uniform): every access of a wave goes to 64 CONSECUTIVE words of one plane -- no LDS bank conflict (the natural layout's stride of
+// two words made every access two-way conflicted: 7.3 % of the LDS pipe's active cycles, profiles/r04/pmc_n2048_eo.json) -- and with the
+// planes 4 KiB-aligned the address of a rotated coefficient is one add, one and-or from a per-polynomial lane constant.
 // The kernel this one replaced (split by the TOP index bit, rounds 2-4) and every variant measured on the way are in profiles/HISTORY.md.
 #pragma once
 
@@ -49,12 +55,18 @@ struct EoTw {
 
 struct EoLds {
     typedef Geo<10> G;   // geometry of a parity's 512-point sub-network
+    // layout: [accumulators of all gates: 16 KiB each, so that every parity plane is 4 KiB-aligned][stage tables][per gate: rotation amounts, two
+    // exchange buffer pairs, arrival counters]
+    static constexpr size_t ACC = (size_t)2 * 2048 * 4;
     static constexpr size_t TW = (size_t)EoTw::LDS_CPLX * sizeof(cplx);
     static constexpr size_t XB = (size_t)2 * G::XSLOTS * sizeof(double);            // one wave's re + im exchange buffers: hold 512 cplx
     static constexpr size_t FLAGS = 16;       // two arrival counters per gate
     __host__ __device__ static constexpr size_t abar_bytes(int npad) { return ((size_t)npad * 2 + 15) / 16 * 16; }      // rotation amounts as u16
-    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return (size_t)2 * 2048 * 4 + abar_bytes(npad) + 2 * XB + FLAGS; }
+    __host__ __device__ static constexpr size_t rest_bytes(int npad) { return abar_bytes(npad) + 2 * XB + FLAGS; }
+    __host__ __device__ static constexpr size_t gate_bytes(int npad) { return ACC + rest_bytes(npad); }
     __host__ __device__ static constexpr size_t bytes(int gates, int npad) { return TW + (size_t)gates * gate_bytes(npad); }
+    // word of coefficient c (0 <= c < 2048) inside a polynomial's 2048 words
+    __host__ __device__ static constexpr int plane_word(int c) { return ((c & 1) << 10) | (c >> 1); }
 };
 
 struct EoArgs {
@@ -107,7 +119,7 @@ __device__ __forceinline__ void eo_inv_pass3(double (&re)[R], double (&im)[R], c
 
 template <int L, int BGBIT, int KS_T, int KS_BB, int KSQ, int GATES>
 __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea) {
-    constexpr int LOGN = 11, N = 2048, P = 1024, R = 8, NT = 128 * GATES;
+    constexpr int LOGN = 11, N = 2048, R = 8, NT = 128 * GATES;
     typedef Geo<10> G;   // geometry of a parity's 512-point sub-network
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3, "three digit rows of a polynomial are transformed side by side");
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = wave % GATES;          // the two parities of a gate share a SIMD (waves w, w + GATES)
     const int H = wave / GATES;
-    cplx* tw = reinterpret_cast<cplx*>(smem);
+    cplx* tw = reinterpret_cast<cplx*>(smem + (size_t)GATES * EoLds::ACC);
     for (int idx = tid; idx < EoTw::LDS_CPLX; idx += NT) tw[idx] = ea.etw[EoTw::P1 + idx];
     // this parity's tables, addressed with Geo<10>'s per-direction offsets where a device function expects them
     const cplx* tw_fwd12 = tw + (size_t)H * 7 * 64 - G::TW_P1;                                   // + G::TW_P1 -> P1[H]; P2 is not contiguous with it here:
@@ -134,14 +146,17 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     const GateIo io = gate_io(a, g);
     const bool live = g_raw < a.count && io.ok;
 
-    unsigned char* gbase = smem + EoLds::TW + (size_t)slot * EoLds::gate_bytes(a.npad);
-    uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);                                  // [2][N]
-    uint16_t* abar = reinterpret_cast<uint16_t*>(gbase + (size_t)2 * N * 4);
-    double* xb0 = reinterpret_cast<double*>(gbase + (size_t)2 * N * 4 + EoLds::abar_bytes(a.npad));
+    uint32_t* accbuf = reinterpret_cast<uint32_t*>(smem + (size_t)slot * EoLds::ACC);        // [2 polynomials][2 parity planes][1024]
+    unsigned char* gbase = smem + (size_t)GATES * EoLds::ACC + EoLds::TW + (size_t)slot * EoLds::rest_bytes(a.npad);
+    uint16_t* abar = reinterpret_cast<uint16_t*>(gbase);
+    double* xb0 = reinterpret_cast<double*>(gbase + EoLds::abar_bytes(a.npad));
     double* xb1 = xb0 + 2 * G::XSLOTS;
     double* wbuf = H ? xb1 : xb0;     // the buffer pair this wave owns (writes next); ownership swaps after every trade
     double* rbuf = H ? xb0 : xb1;     // the partner's (read after its arrival)
-    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + EoLds::gate_bytes(a.npad) - EoLds::FLAGS);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + EoLds::rest_bytes(a.npad) - EoLds::FLAGS);
+    // LDS byte address of this gate's accumulator: the and-or addressing of the gather needs the planes 4 KiB-aligned (dynamic LDS starts at 0)
+    const unsigned acc_lds = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)accbuf;
+    if (acc_lds & 4095u) { if (tid == 0 && a.fault) *a.fault = 1; return; }
     if (lane0 == 0) flags[H] = 0u;
     const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + H);
     const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - H));
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
         const int bbar = (int)abar[n];
         for (int c = lane0 + 64 * H; c < 2 * N; c += 128) {
             const int e = (c + bbar) & (2 * N - 1);
-            accbuf[c] = c < N ? ((e >> LOGN) ? 0xE0000000u : 0x20000000u) : 0u;
+            accbuf[(c & N) | EoLds::plane_word(c & (N - 1))] = c < N ? ((e >> LOGN) ? 0xE0000000u : 0x20000000u) : 0u;
         }
     }
     __syncthreads();
@@ -281,19 +296,36 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
             for (int m = 0; m < R; m++) tH[m] = gtwist0[m * 64 + ln];
             uint32_t ure[R], uim[R];
             {
-                const int e0 = (2 * ln + H - r) * 4;                     // 4 (i - r) for m = 0; a lane's points are 512 bytes apart, re / im 4096
-                const unsigned char* pb = reinterpret_cast<const unsigned char*>(poly);
+                // rotated gather (math.rs:85-132) and decomposition offset (math.rs:300-326).  Coefficient c = 2 (ln + 64 k) + H, k < 16 (k >= 8: the
+                // imaginary parts, c + 1024).  (X^r p)[c] = +- p[(c - r) mod N], and c - r = 2 (ln + 64 k + s) + q with q = (H - r) & 1, s = (H - r) >> 1:
+                // plane q, word (ln + s + 64 k) & 1023, negated iff bit 10 of ln + s + 64 k is set.  Own coefficient: plane H, word ln + 64 k.
+                const int hr = H - r;
+                unsigned rot_plane = acc_lds + (unsigned)h * (N * 4) + (unsigned)(hr & 1) * 4096u;      // wave-uniform; the and-or takes it from a VGPR
+                asm volatile("" : "+v"(rot_plane));
+                const unsigned tb = (unsigned)(ln + (hr >> 1)) * 4u;
+                const uint32_t* own = poly + H * 1024 + ln;
+                // all addresses, then all reads (16 rotated + 16 own, the latter as 8 two-word reads), then the arithmetic: 6 integer instructions per
+                // coefficient up to the decomposition offset (add, and-or, sign, two subtractions, xor-add) where the natural layout took 9
+                uint32_t v[2 * R], sg[2 * R], mo[2 * R];
 #pragma unroll
-                for (int m = 0; m < R; m++) {
-                    const int c0 = 2 * (ln + 64 * m) + H, c1 = c0 + 1024;
-                    const int t0 = e0 + 512 * m, t1 = t0 + 4096;
-                    // (the aligned 8-byte pair + a select instead of the 4-byte read at a stride of two words measured slower: 16.00 vs 15.49 ms)
-                    const uint32_t v0 = *reinterpret_cast<const uint32_t*>(pb + (t0 & (4 * N - 4)));
-                    const uint32_t v1 = *reinterpret_cast<const uint32_t*>(pb + (t1 & (4 * N - 4)));
-                    const uint32_t sg0 = (uint32_t)((int32_t)((uint32_t)t0 << (31 - LOGN - 2)) >> 31);     // all ones iff bit LOGN of (i - r) is set
-                    const uint32_t sg1 = (uint32_t)((int32_t)((uint32_t)t1 << (31 - LOGN - 2)) >> 31);
-                    ure[m] = ((((v0 ^ sg0) - sg0) - poly[c0]) + M) ^ M;
-                    uim[m] = ((((v1 ^ sg1) - sg1) - poly[c1]) + M) ^ M;
+                for (int k = 0; k < 2 * R; k++) {
+                    const unsigned t = tb + 256u * k;
+                    unsigned addr;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "s"(0xffcu), "v"(rot_plane));
+                    sg[k] = (uint32_t)((int32_t)(t << 19) >> 31);       // all ones iff bit 12 of the byte offset = bit 10 of the word index
+                    v[k] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * R; k++) {
+                    mo[k] = M - own[64 * k];
+                    asm("" : "+v"(mo[k]));      // (keeps "(M - own) - sign" from being re-associated into one more bit-field extract and an or)
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * R; k++) {
+                    uint32_t x;                                                     // (+-v - own) + M = (v ^ sign) + ((M - own) - sign)
+                    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(x) : "v"(v[k]), "v"(sg[k]), "v"(mo[k] - sg[k]));
+                    const uint32_t u = x ^ M;
+                    if (k < R) ure[k] = u; else uim[k - R] = u;
                 }
             }
             EO_STAMP(0);
@@ -393,10 +425,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
                     const double vr = re[m], vi = im[m];
                     // (re, im) * (c, s): re c - im s, im c + re s   (spqlios-fft-impl.cpp:390-395); the 2/N of fft_processor_spqlios.cpp:158 is in the table
                     const double rc = vr * wt.w[m].x, ic = vi * wt.w[m].x, rs = vr * wt.w[m].y, is = vi * wt.w[m].y;
-                    const int c = 2 * (lane + 64 * m) + H;
-                      // lone waves wait on the add's completion, loses 2 % with it)
-                    __hip_atomic_fetch_add(&poly[c], trunc_to_torus(rc - is), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(&poly[c + P], trunc_to_torus(ic + rs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    // coefficients 2 (lane + 64 m) + H and + 1024: words lane + 64 m and + 512 of this parity's plane.  ds_add_u32: no read-back through
+                    // the wave (14.59 -> 14.52 ms per 1024 gates; the latency kernel, whose lone waves wait on the add's completion, loses 2 % with it)
+                    uint32_t* w = poly + H * 1024 + lane + 64 * m;
+                    __hip_atomic_fetch_add(w, trunc_to_torus(rc - is), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(w + 512, trunc_to_torus(ic + rs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
             // (my accumulator words are published by my next arrival -- the other component's trade / the next step's first row -- which the
@@ -408,6 +441,18 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
     if (H) steps(std::true_type{}); else steps(std::false_type{});
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();      // the last accumulator update has no arrival behind it: both parities' words must be visible below
+    {   // parity planes -> natural coefficient order for what follows (output, sample extract, key switch): each thread of the gate moves 32 words
+        uint32_t nat[4 * R];
+#pragma unroll
+        for (int k = 0; k < 4 * R; k++) {
+            const int c = lane0 + 64 * H + 128 * k;
+            nat[k] = accbuf[(c & N) | EoLds::plane_word(c & (N - 1))];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4 * R; k++) accbuf[lane0 + 64 * H + 128 * k] = nat[k];
+    }
+    __syncthreads();
 #ifdef RTFHE_WG_STAMPS
     if (a.dbg && blockIdx.x == 0 && lane0 == 0)
         for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];

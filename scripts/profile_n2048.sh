@@ -1,14 +1,13 @@
 #!/bin/bash
 # rocprofv3 PMC passes of the N = 2048 kernel on a 1024-gate batch: counters per launch -> gpurun_out/profiles_n2048/pmc_n2048_<kernel>.json
-# usage: profile_n2048.sh [halves|eo]   (which split RTFHE_N2048_KERNEL selects; default: the library's default for a full round)
+# usage: profile_n2048.sh [eo]   (RTFHE_LIB=build/ab/<variant>.so in the environment profiles a variant build instead of the shipped library)
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_n2048
 mkdir -p $OUT $REPO/gpurun_out/profiles_n2048
 cd /tmp && export TMPDIR=/tmp
 export RTFHE_N=2048 RTFHE_SKIP_STAGES=1
-KERN=${1:-halves}
-export RTFHE_N2048_KERNEL=$KERN
+KERN=${1:-eo}
 OUT=$OUT/$KERN; mkdir -p $OUT
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE" FETCH_SIZE WRITE_SIZE; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)

@@ -88,7 +88,7 @@ def test_scatter_bootstrap_gather_world2(count, op_name):
 @pytest.mark.parametrize("count", [7, 2, 0])
 def test_scatter_bootstrap_gather_world3_ragged_and_empty_ranks(count):
     """World size 3: 7 gates = 2 + 2 + 3 (ragged); 2 gates = 0 + 1 + 1 -- the ROOT itself gets no gate and still scatters and gathers;
-    0 gates: nobody computes, everybody returns.  The root posts its sends and receives before it computes (shard.py: run)."""
+    0 gates: nobody computes, everybody returns.  The root posts its sends, launches its own shard and only then posts the receives of the results (shard.py: run explains the order)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
