@@ -77,10 +77,11 @@ def ntt_dp_wave_instr_per_cmux(N=1024, l=3):
     transforms 1024 points, 16 per lane: 10 stages x 8 butterflies x (product + 2 sums)."""
     R, stages = 16, 10
     modmul, norm = 6, 3
-    fwd = stages * (R // 2) * (modmul + 2) + 2 * R * norm               # renormalised after stages 5 and 10
+    lean = N == 1024                                                    # round 5: one renormalisation per forward transform, four per inverse (rtfhe_ntt.hpp)
+    fwd = stages * (R // 2) * (modmul + 2) + (1 if lean else 2) * R * norm      # renormalised after stage 7 (N = 2048: after stages 5 and 10)
     # decomposition digits times the first stage's single twiddle come from a 64-entry table in LDS (no conversion, no product)
     fwd_digits = fwd - (R // 2) * modmul
-    inv = stages * (R // 2) * (modmul + 2) + 5 * R * norm               # on entry and after stages 3, 6, 9, 10
+    inv = stages * (R // 2) * (modmul + 2) + (4 if lean else 5) * R * norm      # on entry and after stages 4, 8, 10 (N = 2048: 3, 6, 9, 10)
     mac = 2 * R * (modmul + 1)                                          # both components of a key row
     if N == 1024:
         # two waves per gate, each: l rows (digit cvt, transform, products), the swapped component's add, one inverse, magic add

@@ -304,20 +304,27 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_eo(const EoArgs ea
                 asm volatile("" : "+v"(rot_plane));
                 const unsigned tb = (unsigned)(ln + (hr >> 1)) * 4u;
                 const uint32_t* own = poly + H * 1024 + ln;
-                // all addresses, then all reads (16 rotated + 16 own, the latter as 8 two-word reads), then the arithmetic: 6 integer instructions per
-                // coefficient up to the decomposition offset (add, and-or, sign, two subtractions, xor-add) where the natural layout took 9
+                // the 16 own coefficients first (8 two-word reads whose addresses need no arithmetic: their latency covers the address arithmetic of
+                // the rotated reads), then the 16 rotated reads, then the arithmetic: 6 integer instructions per coefficient up to the decomposition
+                // offset (add, and-or, sign, two subtractions, xor-add) where the natural layout took 9
                 uint32_t v[2 * R], sg[2 * R], mo[2 * R];
+#pragma unroll
+                for (int k = 0; k < 2 * R; k++) mo[k] = own[64 * k];
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned addr[2 * R];
 #pragma unroll
                 for (int k = 0; k < 2 * R; k++) {
                     const unsigned t = tb + 256u * k;
-                    unsigned addr;
-                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "s"(0xffcu), "v"(rot_plane));
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr[k]) : "v"(t), "s"(0xffcu), "v"(rot_plane));
                     sg[k] = (uint32_t)((int32_t)(t << 19) >> 31);       // all ones iff bit 12 of the byte offset = bit 10 of the word index
-                    v[k] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
                 }
+                __builtin_amdgcn_sched_barrier(0);     // every rotated read is issued before the first is waited for (the scheduler otherwise waits read by read)
+#pragma unroll
+                for (int k = 0; k < 2 * R; k++) v[k] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr[k]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 2 * R; k++) {
-                    mo[k] = M - own[64 * k];
+                    mo[k] = M - mo[k];
                     asm("" : "+v"(mo[k]));      // (keeps "(M - own) - sign" from being re-associated into one more bit-field extract and an or)
                 }
 #pragma unroll

@@ -51,8 +51,8 @@ __device__ __forceinline__ void cmux_step_ntt(uint32_t* __restrict__ accbuf, int
 #pragma unroll
             for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
             ntt::first_stage_digits(x, t);
-            ntt::forward_a<true>(x, twf, xbuf, lane);
-            ntt::forward_b(x, twf, xbuf, lane);
+            ntt::forward_a<true, true>(x, twf, xbuf, lane);
+            ntt::forward_b<true>(x, twf, xbuf, lane);
             // exact arithmetic: the order of the row sum is irrelevant here (it is not for the FFT mirror)
 #pragma unroll
             for (int q = 0; q < R / 2; q++) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void cmux_step_ntt(uint32_t* __restrict__ accbuf, int
         double x[R];
 #pragma unroll
         for (int m = 0; m < R; m++) x[m] = comp ? s1[m] : s0[m];
-        ntt::inverse(x, twi, xbuf, lane);
+        ntt::inverse<true>(x, twi, xbuf, lane);
         uint32_t* poly = accbuf + comp * N;
 #pragma unroll
         for (int m = 0; m < R; m++) {
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
 #pragma unroll
             for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
             ntt::first_stage_digits(x, t);
-            ntt::forward_a<true>(x, twf, myx, lane);
+            ntt::forward_a<true, true>(x, twf, myx, lane);
             prio_point(2 * jj);
-            ntt::forward_b(x, twf, myx, lane);
+            ntt::forward_b<true>(x, twf, myx, lane);
             prio_point(2 * jj + 1);
 #pragma unroll
             for (int q = 0; q < R / 2; q++) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
         }
         if constexpr (FLAG_SYNC) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();   // both imports done: the exchange buffers are free for the inverse transforms
         prio_point(8);
-        ntt::inverse(x, twi, myx, lane);
+        ntt::inverse<true>(x, twi, myx, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) {       // the new coefficients also stay in registers for the gather that follows
             own[m] = poly[lane + 64 * m] + ntt::to_torus(x[m]);

@@ -111,9 +111,9 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_ntt_wg(const NttBootstrapA
                 t[m] = twf[ntt::TW_DIG + ntt::digit_entry(u1, BGBIT, jj)];
             }
             ntt::first_stage_digits(x, t);
-            ntt::forward_a<true>(x, twf, xbuf, lane);
+            ntt::forward_a<true, true>(x, twf, xbuf, lane);
             if (wave < ROWS - 2) {
-                ntt::forward_b(x, twf, xbuf, lane);
+                ntt::forward_b<true>(x, twf, xbuf, lane);
             } else {
                 ntt::forward_b_send(x, xbuf, lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_ntt_wg(const NttBootstrapA
             const int k = wave - ROWS;
             while (__builtin_amdgcn_readfirstlane(flags[k]) != i + 1) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            ntt::forward_b_receive(x, twf, xbuf, lane);
+            ntt::forward_b_receive<true>(x, twf, xbuf, lane);
         }
         if (macs) {
             // products of the row's spectrum with both components of its key row: the exchange buffer (idle now) takes component 0
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_ntt_wg(const NttBootstrapA
         __syncthreads();
         if (macs) load_row(i + 1 < a.steps ? i + 1 : i);            // lands during the I phase
         if (wave < 2) {
-            // ---- I: component `wave`: the six rows' products summed (each |.| <= 0.625 P), inverse transform, += (trlwe.rs:49-60)
+            // ---- I: component `wave`: the six rows' products summed (<= 5.97 P in all, rtfhe_ntt.hpp), inverse transform, += (trlwe.rs:49-60)
             double* set = wave ? part : set0;
             const double2* p = reinterpret_cast<const double2*>(set) + lane;
 #pragma unroll
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_ntt_wg(const NttBootstrapA
                 x[2 * q] = s.x; x[2 * q + 1] = s.y;
             }
             wave_lds_sync();                                    // all six rows are in registers before slot `wave` becomes the exchange buffer
-            ntt::inverse(x, twi, set + (size_t)wave * ntt::XSLOTS, lane);
+            ntt::inverse<true>(x, twi, set + (size_t)wave * ntt::XSLOTS, lane);
             uint32_t* poly = accbuf + wave * N;
 #pragma unroll
             for (int m = 0; m < R; m++) poly[lane + 64 * m] += ntt::to_torus(x[m]);

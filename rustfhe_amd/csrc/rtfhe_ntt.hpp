@@ -11,10 +11,14 @@
 // Transforms with the negacyclic twist merged into per-block twiddles (zeta_k = psi^bitrev(k)):
 //   forward  Cooley-Tukey butterflies (t = zeta x1 ; x0 +- t), stride N/2 .. 1, natural in  -> bit-reversed out
 //   inverse  Gentleman-Sande butterflies (x0 + x1 ; zeta^-1 (x0 - x1)), stride 1 .. N/2, bit-reversed in -> natural out
-// Bounds (scripts/ntt/model.py runs the same operation sequence on exact integers and asserts them): values are
-// renormalised to |x| <= P/2 after stages 5 and 10 (forward) / on entry and after stages 3, 6, 9, 10 (inverse), which keeps every
-// intermediate below 2^53; the true result of a gate's sum of 2l products is below 2^48.6 < P/2, so the centred
-// residue IS the integer result.  N^-1 is folded into the key's transformed rows.
+// Bounds: doubles hold the values exactly while every |value| < 2^53 = 8.0000001 P.  A modular product returns |r| <= P/2 + 3 |a| |w| 2^-53,
+// a Cooley-Tukey stage therefore grows a bound B to 1.1875 B + P/2, a Gentleman-Sande stage doubles it.  The LEAN schedule (N = 1024 kernels,
+// round 5) renormalises to |x| <= P/2 ONCE inside a forward transform (after stage 7; outputs <= 2.64 P go to the multiply-accumulate as they
+// are, six products sum to <= 5.97 P) and on entry, after stages 4 and 8 and at the end of an inverse (four stages from P/2 reach 8 P exactly
+// below 2^53).  scripts/ntt/model.py proves these bounds for every input (worst_case_bounds) and runs the operation sequence on exact integers.
+// The full schedule (after stages 5 and 10 forward; entry, 3, 6, 9, 10 inverse: 384 FP64-rate instructions per CMUX more) stays for the
+// key transform -- whose outputs must be normalised -- and the N = 2048 kernels (one more stage across the halves).  The true result of a gate's
+// sum of 2l products is below 2^48.6 < P/2, so the centred residue IS the integer result.  N^-1 is folded into the key's transformed rows.
 //
 // One wave per transform, 16 points per lane, three in-register passes (4 + 4 + 2 stages) with two wave-private LDS
 // exchanges: the index geometry (layouts L1/L2/L3, conflict-free slot maps f1/f2) is Geo<11>'s (1024 points, R = 16).
@@ -105,7 +109,7 @@ __device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xb
 // Forward transform in two parts so that a caller can issue its global loads between them (their registers are then
 // not live through passes 1 and 2).  in: layout L1 (x[m] = coefficient lane + 64 m), small integers or |x| < 2^32.
 // out: layout L3 (point (lane << 4) | m), normalised.  tw: LDS forward table.
-template <bool FIRST_STAGE_DONE = false>
+template <bool FIRST_STAGE_DONE = false, bool LEAN = false>
 __device__ __forceinline__ void forward_a(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     double z1[15], z2[15];
 #pragma unroll
@@ -116,9 +120,12 @@ __device__ __forceinline__ void forward_a(double (&x)[R], const double* __restri
     for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
     exchange<1, 2>(x, xbuf, lane);
     fwd_stage<3>(x, z2);
-    normalize_all(x);                 // after stage 5 (and after stage 10): every intermediate stays below 2^53 (model.py)
-    fwd_stage<2>(x, z2); fwd_stage<1>(x, z2); fwd_stage<0>(x, z2);
+    if constexpr (!LEAN) normalize_all(x);     // full schedule: after stage 5 (and after stage 10)
+    fwd_stage<2>(x, z2); fwd_stage<1>(x, z2);
+    if constexpr (LEAN) normalize_all(x);      // lean schedule: after stage 7 only
+    fwd_stage<0>(x, z2);
 }
+template <bool LEAN = false>
 __device__ __forceinline__ void forward_b(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     double z3[12];
 #pragma unroll
@@ -138,7 +145,7 @@ __device__ __forceinline__ void forward_b(double (&x)[R], const double* __restri
         x[m + 1] = x[m] - t;
         x[m] = x[m] + t;
     }
-    normalize_all(x);
+    if constexpr (!LEAN) normalize_all(x);
 }
 __device__ __forceinline__ void forward(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     forward_a(x, tw, xbuf, lane);
@@ -151,6 +158,7 @@ __device__ __forceinline__ void forward_b_send(const double (&x)[R], double* __r
 #pragma unroll
     for (int m = 0; m < R; m++) xbuf[GN::f2(GN::pos2(lane, m))] = x[m];
 }
+template <bool LEAN = false>
 __device__ __forceinline__ void forward_b_receive(double (&x)[R], const double* __restrict__ tw, const double* __restrict__ xbuf, int lane) {
     double z3[12];
 #pragma unroll
@@ -170,7 +178,7 @@ __device__ __forceinline__ void forward_b_receive(double (&x)[R], const double* 
         x[m + 1] = x[m] - t;
         x[m] = x[m] + t;
     }
-    normalize_all(x);
+    if constexpr (!LEAN) normalize_all(x);
 }
 
 // The first stage on decomposition digits: x[m] = digit of coefficient lane + 64 m (m < 8) as a double, t[m] = the digit of coefficient
@@ -191,6 +199,7 @@ __device__ __forceinline__ int digit_entry(uint32_t u, int bits, int j) {
 
 // in: layout L3, |x| < 2^52.  out: layout L1, the centred residue (= the exact integer when |true value| < P/2).
 // tw3: the table the per-lane pass-3 entries are read from (the N = 2048 kernel keeps that part in global memory).
+template <bool LEAN = false>
 __device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict__ tw, const double* __restrict__ tw3,
                                         double* __restrict__ xbuf, int lane) {
     double z1[15], z2[15], z3[12];
@@ -213,21 +222,34 @@ __device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict
 #pragma unroll
     for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
     exchange<3, 2>(x, xbuf, lane);
-    inv_stage<0>(x, z2);
-    normalize_all(x);                 // sums double per stage: renormalise after stages 3, 6, 9 and 10 (model.py)
-    inv_stage<1>(x, z2); inv_stage<2>(x, z2); inv_stage<3>(x, z2);
-    normalize_all(x);
+    if constexpr (LEAN) {             // sums double per stage: four stages from P/2 stay below 2^53 -- renormalise after stages 4, 8 and 10
+        inv_stage<0>(x, z2); inv_stage<1>(x, z2);
+        normalize_all(x);
+        inv_stage<2>(x, z2); inv_stage<3>(x, z2);
+    } else {                          // full schedule: after stages 3, 6, 9 and 10
+        inv_stage<0>(x, z2);
+        normalize_all(x);
+        inv_stage<1>(x, z2); inv_stage<2>(x, z2); inv_stage<3>(x, z2);
+        normalize_all(x);
+    }
 #pragma unroll
     for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
     exchange<2, 1>(x, xbuf, lane);
-    inv_stage<0>(x, z1); inv_stage<1>(x, z1); inv_stage<2>(x, z1);
-    normalize_all(x);
-    inv_stage<3>(x, z1);
+    if constexpr (LEAN) {
+        inv_stage<0>(x, z1); inv_stage<1>(x, z1);
+        normalize_all(x);
+        inv_stage<2>(x, z1); inv_stage<3>(x, z1);
+    } else {
+        inv_stage<0>(x, z1); inv_stage<1>(x, z1); inv_stage<2>(x, z1);
+        normalize_all(x);
+        inv_stage<3>(x, z1);
+    }
     normalize_all(x);
 }
 
+template <bool LEAN = false>
 __device__ __forceinline__ void inverse(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
-    inverse(x, tw, tw, xbuf, lane);
+    inverse<LEAN>(x, tw, tw, xbuf, lane);
 }
 
 // The inverse transform read from a FORWARD table.  psi^N = -1 gives zeta_{nb + b}^-1 = -zeta_{nb + (nb - 1 - b)} on every level
