@@ -79,13 +79,14 @@ def ntt_dp_wave_instr_per_cmux(N=1024, l=3):
     modmul, norm = 6, 3
     lean = N == 1024                                                    # round 5: one renormalisation per forward transform, four per inverse (rtfhe_ntt.hpp)
     fwd = stages * (R // 2) * (modmul + 2) + (1 if lean else 2) * R * norm      # renormalised after stage 7 (N = 2048: after stages 5 and 10)
-    # decomposition digits times the first stage's single twiddle come from a 64-entry table in LDS (no conversion, no product)
-    fwd_digits = fwd - (R // 2) * modmul
     inv = stages * (R // 2) * (modmul + 2) + (4 if lean else 5) * R * norm      # on entry and after stages 4, 8, 10 (N = 2048: 3, 6, 9, 10)
     mac = 2 * R * (modmul + 1)                                          # both components of a key row
     if N == 1024:
-        # two waves per gate, each: l rows (digit cvt, transform, products), the swapped component's add, one inverse, magic add
-        row = R // 2 + fwd_digits + mac                                 # conversions of the stage's other input only
+        # the first TWO stages act on decomposition digits and read every digit x twiddle product from 64-entry tables in LDS: per four points
+        # one conversion and eight sums (rtfhe_ntt.hpp, first_two_stages_digits); stages 3..10 are butterflies, one renormalisation
+        fwd_digits = (R // 4) * (1 + 8) + (stages - 2) * (R // 2) * (modmul + 2) + R * norm
+        # two waves per gate, each: l rows (two table stages, transform, products), the swapped component's add, one inverse, magic add
+        row = fwd_digits + mac
         wave = l * row + R + inv + R
         return {"total": 2 * wave, "per_wave": wave, "loop_static": row + R + inv + R, "forward": fwd_digits, "inverse": inv, "mac_row": mac}
     if N == 2048:
@@ -925,14 +926,59 @@ def run_rank(args):
     eng.close()
 
 
+def run_config3_c_abi(args):
+    """BASELINE configs[2] in ONE process behind the C ABI (builder-side tool; the driver's multi-GPU runs are one process per GPU): a
+    multi-device context over --devices, 8192 gates per device resident on devices[0], every step = rtfhe_gate_batch_dev on that context
+    (the library scatters over xGMI, bootstraps on every device, gathers; rustfhe_amd/csrc/rtfhe_multi.hip).  Prints one JSON line."""
+    import numpy as np
+    import torch
+    import rustfhe_amd as R
+    devs = [int(d) for d in args.devices.split(",")]
+    params = R.Params()
+    key0, key1, bk, ksk = R.keygen(params, 20211003)
+    G = (args.gates if args.gates else 8192) * len(devs)
+    gpu = torch.device("cuda", devs[0])
+    torch.cuda.set_device(gpu)
+    eng = R.Engine(params, devices=devs)
+    try:
+        eng.load_bk_torus(bk)
+        eng.load_ksk(ksk)
+        rng = np.random.default_rng(3)
+        b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
+        d0 = torch.from_numpy(R.encrypt_bits(params, key0, b0, 1).view(np.int32)).to(gpu)
+        d1 = torch.from_numpy(R.encrypt_bits(params, key0, b1, 2).view(np.int32)).to(gpu)
+        do = torch.empty_like(d0)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(args.warmup):
+            eng.gate_batch_dev(R.NAND, d0, d1, do, G, st)
+        eng.sync(st)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.gate_batch_dev(R.NAND, d0, d1, do, G, st)
+        eng.sync(st)
+        elapsed = time.perf_counter() - t0
+        ok = bool(np.array_equal(R.decrypt_bits(params, key0, do.cpu().numpy().view(np.uint32)), 1 - (b0 & b1)))
+        print(json.dumps({"metric": "HomNAND gates/sec (whole node), N=1024", "value": round(G * args.steps / elapsed, 1), "unit": "gates/s",
+                          "n_gpus": len(set(devs)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "batch of %d HomNAND gates resident on device %d, sharded over a multi-device CONTEXT of %d entries by "
+                                                 "rtfhe_gate_batch_dev (C ABI; BASELINE configs[2])" % (G, devs[0], len(devs)),
+                                     "devices": devs, "device_bytes_per_entry": [eng.memory_bytes(d) for d in range(len(devs))]},
+                          "outputs_decrypt_correctly": ok}), flush=True)
+    finally:
+        eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "config3", "config3-c-abi"], default="config2",
                     help="config2 (default, BASELINE configs[1]): independent 1024-gate batches per GPU; config3 (BASELINE configs[2]): "
-                         "8192 gates per GPU scattered from / gathered to rank 0 inside the timed step")
+                         "8192 gates per GPU scattered from / gathered to rank 0 inside the timed step; config3-c-abi: the same batch sharded "
+                         "inside the library by a multi-device context over --devices, one process")
+    ap.add_argument("--devices", default="0", help="config3-c-abi: comma-separated device ids of the multi-device context (an id may repeat)")
     ap.add_argument("--gates", type=int, default=0, help="gates per GPU per step (default 1024, config3: 8192)")
     ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact"], default="fft64-mirror",
                     help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
@@ -947,6 +993,8 @@ def main():
         sys.exit(cpu_baseline_child(args.cpu_baseline_child, args.cpu_gates_per_thread))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.workload == "config3-c-abi":
+        return run_config3_c_abi(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args))                      # parent: spawn the ranks, never touch the GPU
     if "WORLD_SIZE" not in os.environ and not os.environ.get("RTFHE_BENCH_INNER") and not under_profiler():

@@ -33,7 +33,7 @@ void ntt_fill_table(double* d, const std::vector<uint64_t>& z) {
     }
 }
 
-// digit table: entry e = (e as a signed 6-bit value) * zeta_1 mod P, centred
+// digit table: entry e = (e as a signed 6-bit value) * c mod P, centred
 void ntt_fill_digits(double* d, uint64_t zeta1) {
     for (int e = 0; e < ntt::DIGITS; e++) {
         const int sdig = e < ntt::DIGITS / 2 ? e : e - ntt::DIGITS;
@@ -50,7 +50,9 @@ std::vector<double> ntt_device_table() {
     std::vector<double> t(ntt::TW_TOTAL, 0.0);
     ntt_fill_table(t.data(), zeta);
     ntt_fill_table(t.data() + ntt::TW_DIR_PAD, zinv);
-    ntt_fill_digits(t.data() + ntt::TW_DIG, zeta[1]);
+    // the five digit tables of the first two stages: zeta_1; zeta_2, zeta_3 (the two blocks of stage 2); zeta_2 zeta_1, zeta_3 zeta_1
+    const uint64_t coeff[ntt::DIG_TABLES] = {zeta[1], zeta[2], zeta[3], mulmod_p(zeta[2], zeta[1]), mulmod_p(zeta[3], zeta[1])};
+    for (int k = 0; k < ntt::DIG_TABLES; k++) ntt_fill_digits(t.data() + ntt::TW_DIG + k * ntt::DIGITS, coeff[k]);
     return t;
 }
 

@@ -38,20 +38,15 @@ __device__ __forceinline__ void cmux_step_ntt(uint32_t* __restrict__ accbuf, int
         }
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
-            double x[R], t[R / 2];
-#pragma unroll
-            for (int m = 0; m < R / 2; m++) {
-                x[m] = (double)decomp_digit(u[m], BGBIT, jj);
-                t[m] = twf[ntt::TW_DIG + ntt::digit_entry(u[m + R / 2], BGBIT, jj)];
-            }
+            double x[R];
             const double2* b0p = ntt_bk_row(bk_i, h * L + jj, 0, lane);
             const double2* b1p = ntt_bk_row(bk_i, h * L + jj, 1, lane);
             // key rows requested up front (measured: 13.3 ms vs 14.3 ms per 1024 gates when requested after pass 2)
             double2 b0[R / 2], b1[R / 2];
 #pragma unroll
             for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
-            ntt::first_stage_digits(x, t);
-            ntt::forward_a<true, true>(x, twf, xbuf, lane);
+            ntt::first_two_stages_digits(x, u, BGBIT, jj, twf + ntt::TW_DIG);
+            ntt::forward_a<2, true>(x, twf, xbuf, lane);
             ntt::forward_b<true>(x, twf, xbuf, lane);
             // exact arithmetic: the order of the row sum is irrelevant here (it is not for the FFT mirror)
 #pragma unroll
@@ -252,19 +247,14 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
         for (int m = 0; m < R; m++) { s0[m] = 0.0; s1[m] = 0.0; }
 #pragma unroll 1
         for (int jj = 0; jj < L; jj++) {
-            double x[R], t[R / 2];
-#pragma unroll
-            for (int m = 0; m < R / 2; m++) {
-                x[m] = (double)decomp_digit(u[m], BGBIT, jj);
-                t[m] = twf[ntt::TW_DIG + ntt::digit_entry(u[m + R / 2], BGBIT, jj)];
-            }
+            double x[R];
             const double2* b0p = ntt_bk_row(bk_i, side * L + jj, 0, lane);
             const double2* b1p = ntt_bk_row(bk_i, side * L + jj, 1, lane);
             double2 b0[R / 2], b1[R / 2];
 #pragma unroll
             for (int q = 0; q < R / 2; q++) { b0[q] = b0p[q * 64]; b1[q] = b1p[q * 64]; }
-            ntt::first_stage_digits(x, t);
-            ntt::forward_a<true, true>(x, twf, myx, lane);
+            ntt::first_two_stages_digits(x, u, BGBIT, jj, twf + ntt::TW_DIG);
+            ntt::forward_a<2, true>(x, twf, myx, lane);
             prio_point(2 * jj);
             ntt::forward_b<true>(x, twf, myx, lane);
             prio_point(2 * jj + 1);

@@ -101,17 +101,14 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_ntt_wg(const NttBootstrapA
             const int h = wave / L, jj = wave - h * L;
             const uint32_t* poly = accbuf + h * N;
             if (wave >= ROWS - 2) __builtin_amdgcn_s_setprio(3);    // the waves that hand over must not be starved by waves 0, 1
-            double t[R / 2];
+            uint32_t u[R];
 #pragma unroll
-            for (int m = 0; m < R / 2; m++) {
-                const int c0 = lane + 64 * m, c1 = c0 + N / 2;
-                const uint32_t u0 = ((rotated_coef<LOGN>(poly, c0, r) - poly[c0]) + M) ^ M;
-                const uint32_t u1 = ((rotated_coef<LOGN>(poly, c1, r) - poly[c1]) + M) ^ M;
-                x[m] = (double)decomp_digit(u0, BGBIT, jj);
-                t[m] = twf[ntt::TW_DIG + ntt::digit_entry(u1, BGBIT, jj)];
+            for (int m = 0; m < R; m++) {
+                const int c = lane + 64 * m;
+                u[m] = ((rotated_coef<LOGN>(poly, c, r) - poly[c]) + M) ^ M;
             }
-            ntt::first_stage_digits(x, t);
-            ntt::forward_a<true, true>(x, twf, xbuf, lane);
+            ntt::first_two_stages_digits(x, u, BGBIT, jj, twf + ntt::TW_DIG);
+            ntt::forward_a<2, true>(x, twf, xbuf, lane);
             if (wave < ROWS - 2) {
                 ntt::forward_b<true>(x, twf, xbuf, lane);
             } else {

@@ -42,11 +42,14 @@ constexpr int TW_P2 = TW_P1 + 15;
 constexpr int TW_P3 = TW_P2 + 15 * 16;
 constexpr int TW_DIR = TW_P3 + 12 * 64;   // 1023 = N - 1 zetas
 constexpr int TW_DIR_PAD = 1024;          // keep the inverse table 16-byte aligned
-// digit table [64]: entry e = (e as a signed 6-bit digit) * zeta_1 mod P, centred.  The first forward stage multiplies decomposition
-// DIGITS (64 possible values, Bgbit = 6) by the single twiddle zeta_1: one LDS read replaces the conversion and the 6-instruction product
+// digit tables [5][64]: entry e of table k = (e as a signed 6-bit digit) * c_k mod P, centred, for c = zeta_1, zeta_2, zeta_3, zeta_2 zeta_1,
+// zeta_3 zeta_1.  The first TWO forward stages act on decomposition DIGITS (64 possible values, Bgbit = 6) and involve three twiddles only
+// (zeta_1; zeta_2 and zeta_3 for the two blocks of stage 2): every product of a digit with a twiddle (or a product of two) is one LDS read
+// instead of a conversion and 6-instruction modular products (first_two_stages_digits).  Table 0 alone serves the N = 2048 kernels' first stage.
 constexpr int DIGITS = 64;
+constexpr int DIG_TABLES = 5;
 constexpr int TW_DIG = 2 * TW_DIR_PAD;
-constexpr int TW_TOTAL = TW_DIG + DIGITS;
+constexpr int TW_TOTAL = TW_DIG + DIG_TABLES * DIGITS;
 constexpr int XSLOTS = GN::XSLOTS;        // 1088 doubles
 
 __device__ __forceinline__ double modmul(double a, double w) {
@@ -109,13 +112,14 @@ __device__ __forceinline__ void exchange(double (&x)[R], double* __restrict__ xb
 // Forward transform in two parts so that a caller can issue its global loads between them (their registers are then
 // not live through passes 1 and 2).  in: layout L1 (x[m] = coefficient lane + 64 m), small integers or |x| < 2^32.
 // out: layout L3 (point (lane << 4) | m), normalised.  tw: LDS forward table.
-template <bool FIRST_STAGE_DONE = false, bool LEAN = false>
+template <int STAGES_DONE = 0, bool LEAN = false>
 __device__ __forceinline__ void forward_a(double (&x)[R], const double* __restrict__ tw, double* __restrict__ xbuf, int lane) {
     double z1[15], z2[15];
 #pragma unroll
     for (int e = 0; e < 15; e++) z1[e] = tw[TW_P1 + e];
-    if constexpr (!FIRST_STAGE_DONE) fwd_stage<3>(x, z1);
-    fwd_stage<2>(x, z1); fwd_stage<1>(x, z1); fwd_stage<0>(x, z1);
+    if constexpr (STAGES_DONE < 1) fwd_stage<3>(x, z1);
+    if constexpr (STAGES_DONE < 2) fwd_stage<2>(x, z1);
+    fwd_stage<1>(x, z1); fwd_stage<0>(x, z1);
 #pragma unroll
     for (int e = 0; e < 15; e++) z2[e] = tw[TW_P2 + e * 16 + (lane >> 2)];
     exchange<1, 2>(x, xbuf, lane);
@@ -181,15 +185,22 @@ __device__ __forceinline__ void forward_b_receive(double (&x)[R], const double* 
     if constexpr (!LEAN) normalize_all(x);
 }
 
-// The first stage on decomposition digits: x[m] = digit of coefficient lane + 64 m (m < 8) as a double, t[m] = the digit of coefficient
-// lane + 64 (m + 8) times zeta_1, read from the digit table (the same centred residue modmul() returns for so small an input).
-// forward_a<true> continues with stage 2.
-__device__ __forceinline__ void first_stage_digits(double (&x)[R], const double (&t)[R / 2]) {
+// The first TWO stages on decomposition digits.  u[m] = the pre-masked decomposition word of coefficient lane + 64 m; with a, b, c, d the digits
+// j of coefficients lane + 64 g + {0, 256, 512, 768} (registers g, g + 4, g + 8, g + 12), the Cooley-Tukey stages 1 (stride 512, zeta_1) and 2
+// (stride 256, zeta_2 for the lower block, zeta_3 for the upper) give
+//   x[g]     = (a + z1 c) + (z2 b + z2 z1 d)        x[g + 4]  = (a + z1 c) - (z2 b + z2 z1 d)
+//   x[g + 8] = (a - z1 c) + (z3 b - z3 z1 d)        x[g + 12] = (a - z1 c) - (z3 b - z3 z1 d)
+// with every product read from a digit table (centred residues, |.| <= P/2: |x| <= 1.5 P + 32): 1 conversion + 8 sums per four points where
+// a table for stage 1 and modular products for stage 2 took 22 FP64-rate instructions.  forward_a<2> continues with stage 3.
+__device__ __forceinline__ int digit_entry(uint32_t u, int bits, int j);
+__device__ __forceinline__ void first_two_stages_digits(double (&x)[R], const uint32_t (&u)[R], int bits, int jj, const double* __restrict__ dig) {
 #pragma unroll
-    for (int m = 0; m < R / 2; m++) {
-        const double lo = x[m];
-        x[m] = lo + t[m];
-        x[m + R / 2] = lo - t[m];
+    for (int g = 0; g < R / 4; g++) {
+        const int ib = digit_entry(u[g + 4], bits, jj), ic = digit_entry(u[g + 8], bits, jj), id = digit_entry(u[g + 12], bits, jj);
+        const double a = (double)decomp_digit(u[g], bits, jj);
+        const double zc = dig[ic], z2b = dig[DIGITS + ib], z3b = dig[2 * DIGITS + ib], z2d = dig[3 * DIGITS + id], z3d = dig[4 * DIGITS + id];
+        const double s = a + zc, t = a - zc, p = z2b + z2d, q = z3b - z3d;
+        x[g] = s + p; x[g + 4] = s - p; x[g + 8] = t + q; x[g + 12] = t - q;
     }
 }
 // byte offset of a digit's entry in the digit table: field j (from the top) of the pre-masked word u = (x + M) ^ M, times 8

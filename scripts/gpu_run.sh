@@ -6,7 +6,7 @@
 #   smoke            __graft_entry__.smoke()
 #   bench            python bench.py (default flags: headline + cpu baseline + secondary)
 #   bench20          python bench.py --steps 20 --warmup 5 (the driver's flags)
-#   config3          bench.py --workload config3 on one GPU
+#   config3[:D]      bench.py --workload config3 on one GPU (RCCL harness); with D: --workload config3-c-abi over D entries naming GPU 0 (C-ABI sharding)
 #   ntt              bench.py --backend ntt-exact
 #   sweep[:N[:backend]]   scripts/sweep.py over the usual batch sizes (N = 1024 default, 2048; backend fft|ntt)
 #   circuit          scripts/bench_circuit.py (the adder netlists)
@@ -33,7 +33,9 @@ for step in "$@"; do
     smoke)   run smoke bash -c "timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; rc=\$?; tail -2 $O/smoke.log; exit \$rc" ;;
     bench)   run bench bash -c "timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; rc=\$?; cut -c1-400 $O/bench.json; exit \$rc" ;;
     bench20) run bench20 bash -c "timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2> $O/bench20.err; rc=\$?; cut -c1-400 $O/bench_steps20_warmup5.json; exit \$rc" ;;
-    config3) run config3 bash -c "timeout -k 10 300 python bench.py --workload config3 --steps 3 --warmup 1 ${a1:+--gpus-in-process $a1} > $O/bench_config3${a1:+_dev$a1}.json 2> $O/bench_config3.err; rc=\$?; cut -c1-300 $O/bench_config3${a1:+_dev$a1}.json; exit \$rc" ;;
+    config3) if [ -n "$a1" ]; then devs=$(python3 -c "print(','.join(['0'] * $a1))")
+               run "config3 c-abi x$a1" bash -c "timeout -k 10 300 python bench.py --workload config3-c-abi --devices $devs --steps 3 --warmup 1 > $O/bench_config3_c_abi_$a1.json 2> $O/bench_config3_c_abi.err; rc=\$?; cut -c1-400 $O/bench_config3_c_abi_$a1.json; exit \$rc"
+             else run config3 bash -c "timeout -k 10 300 python bench.py --workload config3 --steps 3 --warmup 1 > $O/bench_config3_1gpu.json 2> $O/bench_config3.err; rc=\$?; cut -c1-300 $O/bench_config3_1gpu.json; exit \$rc"; fi ;;
     ntt)     run ntt bash -c "timeout -k 10 300 python bench.py --backend ntt-exact --no-cpu-baseline > $O/bench_ntt_exact.json 2> $O/bench_ntt.err; rc=\$?; cut -c1-300 $O/bench_ntt_exact.json; exit \$rc" ;;
     sweep)   n=${a1:-1024}; be=${a2:-fft}; sizes=1,256,512,768,1024,1280,1536,2048,4096,8192; [ $n = 2048 ] && sizes=1,256,512,768,1024,2048; [ $be = ntt ] && sizes=1,512,1024
              run sweep env RTFHE_N=$n RTFHE_BACKEND=$be RTFHE_SKIP_STAGES=1 bash -c "timeout -k 10 300 python scripts/sweep.py $sizes > $O/sweep_N${n}_$be.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/sweep_N${n}_$be.log; exit \$rc" ;;

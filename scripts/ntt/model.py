@@ -74,8 +74,9 @@ def worst_case_bounds(rows=6):
         assert b < LIM, "bound %.3f P reaches 2^53" % (b / P)
         worst = max(worst, b)
         return b
-    b = 32                         # decomposition digits
-    for stage in range(1, 11):     # Cooley-Tukey: t = modmul(x1, z); x0 +- t
+    # stages 1 and 2 act on decomposition digits through tables of centred residues: x = a + z1 c +- (z2 b + z2 z1 d), |a| <= 32, every product <= P/2
+    b = chk(32 + 3 * half)
+    for stage in range(3, 11):     # Cooley-Tukey: t = modmul(x1, z); x0 +- t
         b = chk(b + mm(chk(b)))
         if stage in FWD_NORM:
             b = nz(b)
@@ -94,10 +95,25 @@ def normalize(x):
     q = int(np.rint(np.float64(float(x)) * np.float64(PINV)))
     return track(x - q * P)
 
-def forward(a):
+def forward_digits(a):
+    """the device's forward transform of a DIGIT polynomial: stages 1 and 2 from the five digit tables (rtfhe_ntt.hpp, first_two_stages_digits),
+    stages 3..10 as butterflies"""
+    assert all(-32 <= v < 32 for v in a)
+    z1, z2, z3 = ZETA[1], ZETA[2], ZETA[3]
+    tab = [[center(d * c) for d in range(-32, 32)] for c in (z1, z2, z3, z2 * z1 % P, z3 * z1 % P)]
+    x = [0] * N
+    for j in range(N // 4):
+        ai, b, c, d = a[j], a[j + 256], a[j + 512], a[j + 768]
+        zc, z2b, z3b, z2d, z3d = tab[0][c + 32], tab[1][b + 32], tab[2][b + 32], tab[3][d + 32], tab[4][d + 32]
+        s_, t_, p_, q_ = track(ai + zc), track(ai - zc), track(z2b + z2d), track(z3b - z3d)
+        x[j], x[j + 256], x[j + 512], x[j + 768] = track(s_ + p_), track(s_ - p_), track(t_ + q_), track(t_ - q_)
+    return forward(x, first_stage=3)
+
+
+def forward(a, first_stage=1):
     a = list(a)
-    h = N // 2
-    stage = 0
+    h = N // 2 >> (first_stage - 1)
+    stage = first_stage - 1
     while h >= 1:
         nb = N // (2 * h)
         for b in range(nb):
@@ -145,6 +161,7 @@ if __name__ == "__main__":
     # forward really evaluates at odd powers of psi in bit-reversed order
     a = [random.randrange(-32, 32) for _ in range(N)]
     fa = forward(a)
+    assert all((x - y) % P == 0 for x, y in zip(fa, forward_digits(a))), "table stages != butterfly stages"
     for p in (0, 1, 5, 1023):
         root = pow(PSI, 2 * brv(p, LOGN) + 1, P)
         assert (fa[p] - sum(c * pow(root, i, P) for i, c in enumerate(a))) % P == 0
@@ -154,7 +171,7 @@ if __name__ == "__main__":
     acc = [0] * N
     for r_, d_ in zip(rows, digs):
         fr = [center(x * NINV) for x in forward(r_)]
-        fd = forward(d_)
+        fd = forward_digits(d_)
         for k in range(N):
             acc[k] = track(acc[k] + modmul(fd[k], fr[k]))
     out = inverse(acc)
@@ -168,11 +185,11 @@ if __name__ == "__main__":
     for dval, rval in ((-32, -2 ** 31), (31, 2 ** 31 - 1)):
         for alt in (False, True):
             rows = [[rval * (-1 if (alt and i % 2) else 1) for i in range(N)] for _ in range(6)]
-            digs = [[dval * (-1 if (alt and (i // 3) % 2) else 1) for i in range(N)] for _ in range(6)]
+            digs = [[min(31, dval * (-1 if (alt and (i // 3) % 2) else 1)) for i in range(N)] for _ in range(6)]      # digits live in [-32, 31]
             acc = [0] * N
             for r_, d_ in zip(rows, digs):
                 fr = [center(x * NINV) for x in forward(r_)]
-                fd = forward(d_)
+                fd = forward_digits(d_)
                 for k in range(N):
                     acc[k] = track(acc[k] + modmul(fd[k], fr[k]))
             out = inverse(acc)

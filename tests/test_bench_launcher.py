@@ -140,8 +140,8 @@ def test_n2048_parity_split_kernel_executes_the_reference_operation_list(device_
 def test_ntt_opcount_formula():
     import bench
     o = bench.ntt_dp_wave_instr_per_cmux(1024, 3)
-    assert o["forward"] == 640 and o["inverse"] == 832 and o["mac_row"] == 224        # round 4: 688 / 880 (two more renormalisations per row, one per inverse)
-    assert o["per_wave"] == 3480 and o["total"] == 6960 and o["loop_static"] == 1736  # round 4: 7,344 per CMUX
+    assert o["forward"] == 596 and o["inverse"] == 832 and o["mac_row"] == 224        # round 4: 688 + 8 conversions / 880 (two table stages instead of one,
+    assert o["per_wave"] == 3324 and o["total"] == 6648 and o["loop_static"] == 1684  # one renormalisation less per transform); round 4: 7,344 per CMUX
     assert bench.ntt_dp_wave_instr_per_cmux(2048, 3)["total"] == 19968
 
 

@@ -536,3 +536,39 @@ def test_a_callers_own_stream_capture_survives_a_later_larger_batch_on_that_stre
             assert np.array_equal(out_small.cpu().numpy().view(np.uint32), ref)
     assert list(R.decrypt_bits(engine.p, keys.key0, out_large.cpu().numpy().view(np.uint32))) == list(1 - (bits[0] & bits[1]))
     assert launches_per_capture == 1, "a batch inside a caller's capture must be ONE fused kernel node (no scratch buffer in the caller's graph)"
+
+
+def test_second_key_layouts_are_built_by_the_first_batch_that_reads_them(params, keys):
+    """rtfhe_ctx_memory_bytes: loading the keys allocates the canonical spectra (+ the torus form, both key-switch forms, scratch); the layout of
+    the four-wave kernel (N = 1024, tails of 257-768 gates) appears with the first batch whose dispatch reads it -- not at load time, and not for a
+    batch that runs on the two-wave or the latency kernel -- and is rebuilt (same footprint, same words) after the key is loaded again."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    e = R.Engine(p, 0)
+    try:
+        spectra = p.n * 2 * 2 * p.l * (p.N // 2) * 16
+        assert e.memory_bytes() == 0
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        loaded = e.memory_bytes()
+        assert loaded >= spectra + p.bk_words * 4 + 156306144 + 83886080
+        rng = np.random.default_rng(99)
+        b0, b1 = rng.integers(0, 2, 1024), rng.integers(0, 2, 1024)
+        d0 = torch.from_numpy(keys.encrypt_bits(b0).view(np.int32)).cuda()
+        d1 = torch.from_numpy(keys.encrypt_bits(b1).view(np.int32)).cuda()
+        out = torch.empty_like(d0)
+        e.gate_batch_dev(R.NAND, d0, d1, out, 1024); e.sync()       # a full round of the two-wave kernel (and this stream's sample buffer)
+        assert loaded < e.memory_bytes() < loaded + spectra
+        loaded = e.memory_bytes()
+        e.gate_batch_dev(R.NAND, d0, d1, out, 100); e.sync()        # a tail on the latency kernel: still the canonical layout only
+        assert e.memory_bytes() == loaded
+        e.gate_batch_dev(R.NAND, d0, d1, out, 300); e.sync()          # 257-768 gates: four waves per gate, its own layout of the spectra
+        assert e.memory_bytes() == loaded + spectra
+        first = out[:300].clone()
+        e.load_bk_torus(keys.bk_t)                                     # a new key invalidates the layout; the next such batch rebuilds it in place
+        e.gate_batch_dev(R.NAND, d0, d1, out, 300); e.sync()
+        assert e.memory_bytes() == loaded + spectra and torch.equal(out[:300], first)
+        assert keys.decrypt_bits(first.cpu().numpy().view(np.uint32)) == list(1 - (b0[:300] & b1[:300]))
+    finally:
+        e.close()
