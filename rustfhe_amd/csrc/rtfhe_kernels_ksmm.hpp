@@ -20,6 +20,9 @@
 // 64 accumulator registers, key operands of 4 K-steps in flight; K-slices add their parts to the (zeroed) output with wrapping u32
 // atomics (order-free).  The grid is laid out so that all gate groups and slices of a column group share one XCD's L2
 // (blockIdx % 8 == cg % 8 when the column-group count is a multiple of 8: 40 for n = 635).
+// The one-hot operand of a K-step is a function of ONE byte of a gate's rounded coefficient (four 2-bit digits -> four words with one byte
+// set): it is read from a 256-entry table in LDS (one ds_read_b128) instead of being built with 16 shifts and masks per gate tile and K-step
+// -- with four tiles per wave those ~300 VALU cycles per K-step, not the 16 MFMAs (256 cycles), were what a wave waited for (round 5).
 #pragma once
 
 #include "rtfhe_kernels.hpp"
@@ -60,17 +63,31 @@ __global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
         const int g = min((mg * MT + mt) * 16 + r16, a.count - 1);
         src[mt] = a.tlwe1 + (size_t)g * w1 + (size_t)q * quarter;
     }
+    // one-hot operands by digit byte: entry b = { 1 << 8 ((b >> 6) & 3), 1 << 8 ((b >> 4) & 3), 1 << 8 ((b >> 2) & 3), 1 << 8 (b & 3) }
+    __shared__ v4i_t onehot[256];
+#pragma unroll
+    for (int b = lane; b < 256; b += 64)
+        onehot[b] = (v4i_t){(int)(1u << (((b >> 6) & 3) * 8)), (int)(1u << (((b >> 4) & 3) * 8)), (int)(1u << (((b >> 2) & 3) * 8)), (int)(1u << ((b & 3) * 8))};
+    __syncthreads();
     v4i_t acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[mt][j] = (v4i_t){0, 0, 0, 0};
-    const uint4* kp = a.kmat + (size_t)cg * ksteps * 4 * 64 + lane;
-    uint4 ring[PF][4];
+    // Key operands through a buffer resource over this column group's panel (ksteps x 4 KiB < 2^31 bytes): address = panel + scalar K-step offset +
+    // lane * 16 + limb * 1024 as an immediate -- no 64-bit vector address arithmetic per load (it was 126 of the loop's VALU instructions), and the
+    // prefetch index is clamped with scalar arithmetic instead of being branched around (the last PF loads of a slice re-read its last K-step).
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.kmat + (size_t)cg * ksteps * 4 * 64), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
+    auto kload = [&](v4u (&dst)[4], int ks) {
+        const int soff = __builtin_amdgcn_readfirstlane(ks * 4096);
 #pragma unroll
-    for (int t = 0; t < PF; t++)
+        for (int j = 0; j < 4; j++) dst[j] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, lane16 + j * 1024, soff, 0);
+    };
+    v4u ring[PF][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) ring[t][j] = kp[((size_t)(2 * kk_begin + t) * 4 + j) * 64];
+    for (int t = 0; t < PF; t++) kload(ring[t], min(2 * kk_begin + t, ks_end - 1));
     uint4 aw[MT];
 #pragma unroll 1
     for (int kk4 = kk_begin; kk4 < kk_end; kk4 += 4) {       // 4 coefficients per lane group = 8 K-steps per trip
@@ -82,22 +99,15 @@ __global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int t = 2 * e + h, ks = 2 * kk4 + t;
-                uint4 b[4];
+                v4u b[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) b[j] = ring[t % PF][j];
-                if (ks + PF < ks_end) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) ring[t % PF][j] = kp[((size_t)(ks + PF) * 4 + j) * 64];
-                }
+                kload(ring[t % PF], min(ks + PF, ks_end - 1));
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
                     const uint32_t word = (e == 0 ? aw[mt].x : e == 1 ? aw[mt].y : e == 2 ? aw[mt].z : aw[mt].w) + ROUND;
                     const uint32_t byte8 = (word >> (24 - 8 * h)) & 0xffu;         // levels 4h .. 4h+3, most significant first
-                    v4i_t av;
-                    av.x = (int)(1u << (((byte8 >> 6) & 3u) * 8u));
-                    av.y = (int)(1u << (((byte8 >> 4) & 3u) * 8u));
-                    av.z = (int)(1u << (((byte8 >> 2) & 3u) * 8u));
-                    av.w = (int)(1u << ((byte8 & 3u) * 8u));
+                    const v4i_t av = onehot[byte8];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const v4i_t bv = {(int)b[j].x, (int)b[j].y, (int)b[j].z, (int)b[j].w};

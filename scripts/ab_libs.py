@@ -38,15 +38,16 @@ for spec in libs:
     engines.append(e); outs.append(torch.empty_like(d0))
     for kv in envs:
         del os.environ[kv.split("=")[0]]
-times = [[] for _ in libs]
+times, ks_times = [[] for _ in libs], [[] for _ in libs]
 for r in range(rounds + 1):
     for k, e in enumerate(engines):
         e.timer_begin(st)
         for _ in range(3): e.gate_batch_dev(R.NAND, d0, d1, outs[k], G, st)
-        ms, n = e.timer_end(st)
-        if r: times[k].append(ms / 3)
+        ms, ks_ms, n = e.timer_end_detail(st)
+        if r: times[k].append(ms / 3); ks_times[k].append(ks_ms / 3)
 same = all(bool(torch.equal(outs[0], o)) for o in outs[1:])
 for k, path in enumerate(libs):
     t = np.array(times[k])
     print(json.dumps({"lib": names[k], "gates": G, "median_ms": round(float(np.median(t)), 4), "min_ms": round(float(t.min()), 4),
-                      "gates_per_s_median": round(G / np.median(t) * 1e3, 1), "outputs_identical": same}), flush=True)
+                      "gates_per_s_median": round(G / np.median(t) * 1e3, 1), "key_switch_ms_median": round(float(np.median(ks_times[k])), 4),
+                      "outputs_identical": same}), flush=True)
