@@ -188,9 +188,11 @@ def test_exact_int_backend_decrypts_like_mirror(orc, keys):
 
 
 def test_ntt_backend_model():
-    """scripts/ntt/model.py: the NTT backend's operation sequence on exact integers (tables, bounds < 2^53, product == exact)."""
+    """scripts/ntt/model.py: the NTT backend's operation sequence on exact integers (tables incl. the two digit-table stages, product == exact)
+    and the worst-case interval bounds of the lean renormalisation schedule (every intermediate < 2^53 for ANY input)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ntt", "model.py")], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert out.returncode == 0 and lines[0].startswith("worst-case bounds") and lines[-1].startswith("ok"), out.stdout + out.stderr
 
