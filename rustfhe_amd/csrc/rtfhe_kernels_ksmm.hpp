@@ -43,18 +43,27 @@ struct KsMmArgs {
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
-// grid: x = (mg * splitk + slice) * colgroups + cg; one wave per block
+// A workgroup is KSMM_WAVES waves: each owns MT = 4 gate tiles (64 gates) and ALL of them walk the same K-slice of the same column group, so a
+// K-step's key operand is fetched ONCE per workgroup -- cooperatively, a chunk of 4 K-steps (16 KiB) at a time into one of two LDS buffers while
+// the other is being multiplied -- and read from LDS by every wave.  (Round 4's one-wave workgroups each streamed the panel themselves: 0.43 GB
+// from the fabric side for an 84 MB operand per 1,024-gate launch, and the launch waited for exactly that; round 5.)
+// grid: x = (mgb * splitk + slice) * colgroups + cg, mgb = group of 64 * KSMM_WAVES gates
+constexpr int KSMM_WAVES = 8;
+constexpr int KSMM_CHUNK = 4;         // K-steps per LDS chunk (= 2 coefficients per lane group)
 template <int KS_T, int KS_BB>
-__global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
+__global__ __launch_bounds__(64 * KSMM_WAVES, 1) void k_key_switch_mm(const KsMmArgs a) {
     static_assert(KS_T == 8 && KS_BB == 2, "operand packing: 4 levels x 4 digit values per 16-byte operand chunk");
-    constexpr int MT = 4, PF = 4;       // gate tiles per wave; K-steps of key operands in flight
+    constexpr int MT = 4, W = KSMM_WAVES, KC = KSMM_CHUNK, NT = 64 * W;
+    constexpr int CHUNK_V4 = KC * 4 * 64;                 // uint4 per chunk
+    constexpr int PER_THREAD = CHUNK_V4 / NT;             // uint4 a thread stages per chunk
+    static_assert(CHUNK_V4 % NT == 0, "whole uint4 per thread");
     constexpr uint32_t ROUND = 1u << (32 - KS_T * KS_BB - 1);
-    const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = blockIdx.x % a.colgroups, rest = blockIdx.x / a.colgroups;
-    const int slice = rest % a.splitk, mg = rest / a.splitk;
+    const int slice = rest % a.splitk, mg = (rest / a.splitk) * W + wave;      // this wave's group of 64 gates
     const int quarter = a.N / 4, ksteps = a.N / 2;
     const int kk_begin = quarter / a.splitk * slice, kk_end = kk_begin + quarter / a.splitk;     // coefficients (per lane group) of this slice
-    const int ks_end = 2 * kk_end;
     const size_t w1 = (size_t)a.N + 1;
     // the gates whose one-hot rows this lane builds (row r16 of each of the MT tiles); tiles past the batch shadow the last gate
     const uint32_t* src[MT];
@@ -65,57 +74,61 @@ __global__ __launch_bounds__(64, 1) void k_key_switch_mm(const KsMmArgs a) {
     }
     // one-hot operands by digit byte: entry b = { 1 << 8 ((b >> 6) & 3), 1 << 8 ((b >> 4) & 3), 1 << 8 ((b >> 2) & 3), 1 << 8 (b & 3) }
     __shared__ v4i_t onehot[256];
-#pragma unroll
-    for (int b = lane; b < 256; b += 64)
+    __shared__ v4i_t kbuf[2][CHUNK_V4];                   // [buffer][K-step of the chunk][limb][lane]
+    for (int b = tid; b < 256; b += NT)
         onehot[b] = (v4i_t){(int)(1u << (((b >> 6) & 3) * 8)), (int)(1u << (((b >> 4) & 3) * 8)), (int)(1u << (((b >> 2) & 3) * 8)), (int)(1u << ((b & 3) * 8))};
-    __syncthreads();
     v4i_t acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[mt][j] = (v4i_t){0, 0, 0, 0};
-    // Key operands through a buffer resource over this column group's panel (ksteps x 4 KiB < 2^31 bytes): address = panel + scalar K-step offset +
-    // lane * 16 + limb * 1024 as an immediate -- no 64-bit vector address arithmetic per load (it was 126 of the loop's VALU instructions), and the
-    // prefetch index is clamped with scalar arithmetic instead of being branched around (the last PF loads of a slice re-read its last K-step).
+    // The chunk of K-steps [ks0, ks0 + KC) of this column group's panel is CHUNK_V4 consecutive uint4: thread t stages uint4 t, t + NT, ...
+    // through a buffer resource (scalar chunk offset + one lane VGPR + immediates).
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.kmat + (size_t)cg * ksteps * 4 * 64), 0, 0x7fffffff, 0x00020000);
-    const int lane16 = lane * 16;
-    auto kload = [&](v4u (&dst)[4], int ks) {
-        const int soff = __builtin_amdgcn_readfirstlane(ks * 4096);
+    const int tid16 = tid * 16;
+    v4u stage[PER_THREAD];
+    auto fetch_chunk = [&](int ks0) {
+        const int soff = __builtin_amdgcn_readfirstlane(ks0 * 4096);
 #pragma unroll
-        for (int j = 0; j < 4; j++) dst[j] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, lane16 + j * 1024, soff, 0);
+        for (int p = 0; p < PER_THREAD; p++) stage[p] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, tid16 + p * NT * 16, soff, 0);
     };
-    v4u ring[PF][4];
+    auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int t = 0; t < PF; t++) kload(ring[t], min(2 * kk_begin + t, ks_end - 1));
+        for (int p = 0; p < PER_THREAD; p++) kbuf[buf][tid + p * NT] = (v4i_t){(int)stage[p].x, (int)stage[p].y, (int)stage[p].z, (int)stage[p].w};
+    };
+    const int nchunks = (kk_end - kk_begin) * 2 / KC;
+    fetch_chunk(2 * kk_begin);
+    store_chunk(0);
+    __syncthreads();
     uint4 aw[MT];
 #pragma unroll 1
-    for (int kk4 = kk_begin; kk4 < kk_end; kk4 += 4) {       // 4 coefficients per lane group = 8 K-steps per trip
+    for (int c = 0; c < nchunks; c++) {
+        const int kk2 = kk_begin + c * (KC / 2);          // first of the chunk's two coefficients (per lane group)
+        if (c + 1 < nchunks) fetch_chunk(2 * kk2 + KC);   // the next chunk: in flight under this chunk's multiplies
+        if ((c & 1) == 0) {                               // gate words of four coefficients at a time (two chunks)
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-            aw[mt] = make_uint4(src[mt][kk4], src[mt][kk4 + 1], src[mt][kk4 + 2], src[mt][kk4 + 3]);   // rows of N+1 words: 4-byte aligned only
+            for (int mt = 0; mt < MT; mt++)
+                aw[mt] = make_uint4(src[mt][kk2], src[mt][kk2 + 1], src[mt][kk2 + 2], src[mt][kk2 + 3]);   // rows of N+1 words: 4-byte aligned only
+        }
+        const v4i_t* kb = kbuf[c & 1] + lane;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int t = 0; t < KC; t++) {                    // K-step 2 kk + h: coefficient e = t / 2 of the chunk, byte h = t % 2
+            const int h = t & 1;
+            v4i_t b[4];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int t = 2 * e + h, ks = 2 * kk4 + t;
-                v4u b[4];
+            for (int j = 0; j < 4; j++) b[j] = kb[(t * 4 + j) * 64];
 #pragma unroll
-                for (int j = 0; j < 4; j++) b[j] = ring[t % PF][j];
-                kload(ring[t % PF], min(ks + PF, ks_end - 1));
+            for (int mt = 0; mt < MT; mt++) {
+                const uint32_t w0 = (c & 1) ? ((t >> 1) ? aw[mt].w : aw[mt].z) : ((t >> 1) ? aw[mt].y : aw[mt].x);
+                const uint32_t byte8 = ((w0 + ROUND) >> (24 - 8 * h)) & 0xffu;         // levels 4h .. 4h+3, most significant first
+                const v4i_t av = onehot[byte8];
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    const uint32_t word = (e == 0 ? aw[mt].x : e == 1 ? aw[mt].y : e == 2 ? aw[mt].z : aw[mt].w) + ROUND;
-                    const uint32_t byte8 = (word >> (24 - 8 * h)) & 0xffu;         // levels 4h .. 4h+3, most significant first
-                    const v4i_t av = onehot[byte8];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const v4i_t bv = {(int)b[j].x, (int)b[j].y, (int)b[j].z, (int)b[j].w};
-                        acc[mt][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc[mt][j], 0, 0, 0);
-                    }
-                }
+                for (int j = 0; j < 4; j++) acc[mt][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], acc[mt][j], 0, 0, 0);
             }
         }
+        if (c + 1 < nchunks) store_chunk((c + 1) & 1);    // (that buffer's last readers finished chunk c - 1 before the barrier below of iteration c - 1)
+        __syncthreads();
     }
     // D layout of a 16x16 i32 tile: lane holds column lane % 16, rows 4 (lane / 16) + r in register r
     const int col = cg * 16 + r16;

@@ -103,10 +103,12 @@ int launch_ksmat_build(rtfhe_ctx* ctx, const uint32_t* d_raw, int colgroups, hip
 }
 
 int launch_key_switch_mm(rtfhe_ctx* ctx, const BootstrapArgs& a, const uint32_t* samples, hipStream_t s) {
-    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + 16 * KSMM_MT - 1) / (16 * KSMM_MT);
-    // K-slices: enough single-wave blocks to give every SIMD a few (the slices of one launch add into the zeroed output)
+    const int per_block = 16 * KSMM_MT * KSMM_WAVES;      // gates of a workgroup: KSMM_WAVES waves x 4 tiles of 16
+    const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + per_block - 1) / per_block;
+    // K-slices: enough workgroups to give every CU two or three (the slices of one launch add into the zeroed output); a slice is a whole
+    // number of LDS chunks of two coefficients per lane group
     int splitk = 1;
-    while (splitk < 8 && (size_t)mgroups * colgroups * splitk < (size_t)8 * ctx->num_cus && (ctx->p.N / 4) % (8 * splitk) == 0) splitk *= 2;
+    while (splitk < 16 && (size_t)mgroups * colgroups * splitk < (size_t)5 * ctx->num_cus / 2 && (ctx->p.N / 4) % (4 * splitk) == 0) splitk *= 2;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // (no bracketing inside rtfhe_circuit_create's capture: a recorded event would become a graph node and rtfhe_timer_end would then ask
     // a never-recorded event for its time; and a timer that is never ended stops taking events at 4096 pairs)
@@ -117,7 +119,7 @@ int launch_key_switch_mm(rtfhe_ctx* ctx, const BootstrapArgs& a, const uint32_t*
         HIPCHECK(ctx, hipEventRecord(ev_a, s));
     }
     KsMmArgs k{samples, ctx->d_ksmat, a.out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk, a.ops, a.idx0, a.idx1, a.idx_out, a.num_wires};
-    hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64 * KSMM_WAVES), 0, s, k);
     HIPCHECK(ctx, hipGetLastError());
     if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
     ctx->launches++;

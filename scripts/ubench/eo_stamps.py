@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase time shares of the N = 2048 kernel (library built with -DRTFHE_WG_STAMPS into build/ab/stamps.so).
-Phases per CMUX step (summed over both polynomials / components): 0 gather + decomposition words | 1 first stage (own rows, trade with the
-partner half) | 2 sub-transforms of three rows | 3 multiply-accumulate with the key rows | 4 inverse sub-network | 5 last stage across the halves,
-untwist, accumulator update | 6 loop overhead / previous phase's tail.
-With RTFHE_N2048_KERNEL=eo (k_bootstrap_eo): 0 gather | 1 digits, twist, passes 1-2 of three rows with their exchanges | 2 pass 3 + the three row trades |
-3 multiply-accumulate (incl. the wait for the last row) | 4 inverse: trade of the sums + table loads | 5 inverse sub-network, untwist, update | 6 loop top."""
+"""Diagnostic: per-phase time shares of the N = 2048 kernel k_bootstrap_eo (library built with -DRTFHE_WG_STAMPS:
+    python scripts/build_variant.py stamps -DRTFHE_WG_STAMPS   ->  build/ab/stamps.so).
+Phases per CMUX step (summed over both polynomials / components): 0 gather | 1 digits, twist, passes 1-2 of three rows with their exchanges |
+2 pass 3 + the three row trades | 3 multiply-accumulate (incl. the wait for the last row) | 4 inverse: trade of the sums + table loads |
+5 inverse sub-network, untwist, update | 6 loop top."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +25,7 @@ for count in (1024,):
     assert e.L.rtfhe_debug_read_stamps(e.h, out) == 0
     a = np.array(out[:64], np.float64).reshape(8, 8) / 635.0
     np.set_printoptions(linewidth=200, suppress=True)
-    print("count", count, "memtime ticks per step by phase (rows = waves 0..7: halves 0 of gates 0..3, then halves 1)")
+    print("count", count, "memtime ticks per step by phase (rows = waves 0..7: parity 0 of gates 0..3, then parity 1)")
     print(np.round(a).astype(int))
     print("per-step total (wave 0):", int(a[0].sum()), " (wave 4):", int(a[4].sum()))
     print("share of phases, mean over waves:", np.round(a.mean(0) / a.mean(0).sum(), 3))

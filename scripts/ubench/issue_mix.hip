@@ -114,5 +114,9 @@ int main() {
     if (run<39, 6, 4, 4, 1, 1, 104>("k_bootstrap_eo's mix (N = 2048)", out, gsrc, cus)) return 1;
     if (run<39, 6, 3, 4, 1, 1, 104, 2>("... one LDS wait per two units, 312 ds_write", out, gsrc, cus)) return 1;
     if (run<39, 0, 0, 0, 0, 0, 104>("... its FP64 instructions alone", out, gsrc, cus)) return 1;
+    // round 5 (parity planes, 6-instruction gather): per wave and step 4,056 FP64, 547 integer VALU, 360 ds_write (+ ds_add), 442 ds_read, 142 vmem,
+    // 157 salu (profiles/r05/pmc_n2048_eo.json / 2).  Two mixes that bracket it:
+    if (run<39, 5, 3, 4, 1, 2, 104, 2>("k_bootstrap_eo's round-5 mix, lower bracket", out, gsrc, cus)) return 1;
+    if (run<39, 6, 4, 5, 2, 2, 104, 2>("k_bootstrap_eo's round-5 mix, upper bracket", out, gsrc, cus)) return 1;
     return 0;
 }
