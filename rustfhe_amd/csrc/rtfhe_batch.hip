@@ -13,7 +13,7 @@ int ensure_tlwe1(rtfhe_ctx* ctx, rtfhe_ctx::Tlwe1& b, size_t gates) {
     HIPCHECK(ctx, hipDeviceSynchronize());            // earlier launches may still read the old buffer
     if (b.d) HIPCHECK(ctx, hipFree(b.d));
     b.d = nullptr; b.cap = 0;
-    const size_t cap = gates < 1024 ? 1024 : gates;
+    const size_t cap = ((gates < 1024 ? 1024 : gates) + 15) / 16 * 16;      // whole tiles of 16 gates (rtfhe::ext_slot): 16 N + 16 words each
     HIPCHECK(ctx, hipMalloc((void**)&b.d, cap * ((size_t)ctx->p.N + 1) * 4));
     b.cap = cap;
     return 0;

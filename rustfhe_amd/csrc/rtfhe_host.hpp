@@ -203,7 +203,7 @@ inline size_t mode_out_words(const BootstrapArgs& a, int N) { return a.mode == r
 inline BootstrapArgs batch_segment(const rtfhe_ctx* ctx, BootstrapArgs a, size_t off, size_t cnt, size_t out_words) {
     if (a.idx0) { a.ops += off; a.idx0 += off; a.idx1 += off; a.idx_out += off; }
     else { a.in0 += off * ((size_t)a.n + 1); a.in1 += off * ((size_t)a.n + 1); a.out += off * out_words; }
-    if (a.ext) a.ext += off * ((size_t)ctx->p.N + 1);
+    if (a.ext) a.ext_first += (int32_t)off;     // one sample buffer per batch, tiled by batch-wide gate number (rtfhe::ext_slot)
     a.count = (int32_t)cnt;
     return a;
 }
@@ -227,7 +227,7 @@ inline bool split_ok(rtfhe_ctx* ctx, const BootstrapArgs& a, hipStream_t s) {
     return b && (size_t)a.count <= b->cap;      // (the sample buffer is sized by ensure_tlwe1 before any launch or capture)
 }
 // blind_rotate(ctx, a', s) launches the bootstrap kernel(s) of the whole batch with a'.mode = MODE_EXTRACT: every gate's lvl1 sample goes to
-// a'.ext (segments of a batch advance it by N + 1 words per gate) and its output row is zeroed for the key switch's atomics
+// a'.ext in the key switch's operand order (rtfhe::ext_slot; segments of a batch advance ext_first, not the pointer) and its output row is zeroed for the key switch's atomics
 template <typename F>
 int launch_split(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s, F blind_rotate) {
     uint32_t* samples = tlwe1_of(ctx, s)->d;

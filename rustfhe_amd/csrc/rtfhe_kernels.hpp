@@ -25,8 +25,9 @@ struct BootstrapArgs {
     const uint32_t* in0;     // [count][n+1]
     const uint32_t* in1;     // [count][n+1] (may alias in0)
     uint32_t* out;           // MODE_GATE / MODE_EXTRACT: [count][n+1] (or the wire table);  MODE_BLIND_ROTATE: [count][2][N]
-    uint32_t* ext;           // MODE_EXTRACT: lvl1 samples [count][N+1] (a'[0..N), b'), row = gate number within the launch; the gate's
-                             // `out` row is ZEROED (the batch key switch adds its K-slices into it with wrapping atomics)
+    uint32_t* ext;           // MODE_EXTRACT: lvl1 samples (a'[0..N), b') of the whole batch in the batch key switch's operand order (ext_slot
+                             // below), gate number = ext_first + gate number within the launch; the gate's `out` row is ZEROED (the batch key
+                             // switch adds its K-slices into it with wrapping atomics)
     int32_t count;
     int32_t op;
     int32_t n;
@@ -34,6 +35,7 @@ struct BootstrapArgs {
     int32_t mode;
     int32_t ksw;             // padded KSK row width in u32 (multiple of 4)
     int32_t npad;            // per-wave LDS words reserved for the mod-switched mask (>= n+1)
+    int32_t ext_first;       // MODE_EXTRACT: the batch-wide number of this launch's first gate (segments of a batch share one sample buffer)
     // netlist mode (all null for a plain batch): gate g reads rows idx0[g], idx1[g] of in0 (the wire table), applies
     // ops[g] and writes row idx_out[g] of out
     const int32_t* ops;
@@ -44,6 +46,19 @@ struct BootstrapArgs {
     int32_t* fault;          // netlist mode: set to 1 when a gate was skipped for an out-of-range index / unknown opcode
     unsigned long long* dbg;   // diagnostic builds only (RTFHE_WG_STAMPS): per-phase cycle sums of workgroup 0
 };
+
+// Where the split path keeps a batch's lvl1 samples between its two launches: the operand order of k_key_switch_mm (rtfhe_kernels_ksmm.hpp).
+// Tiles of 16 gates, 16 N + 16 words each: [coefficient group kk / 4 (N / 16)][lane = 16 q + gate % 16][kk % 4] for coefficient
+// c = q N/4 + kk, then the 16 b' words -- a wave of the key switch reads the four coefficients of its 64 (gate, q) rows as ONE contiguous
+// KiB.  (Rows of N + 1 words, as the reference stores a TLWE sample, made that read 64 pieces of 16 B in 64 cache lines, re-read by every
+// one of the 40 column groups: 10 GB through the L2 per 8,192 gates, the launch's bound until round 5.)  c == N addresses b'.
+__device__ __forceinline__ size_t ext_tile_words(int N) { return 16 * (size_t)N + 16; }
+__device__ __forceinline__ uint32_t* ext_slot(uint32_t* ext, int g, int c, int N) {
+    uint32_t* tile = ext + (size_t)(g >> 4) * ext_tile_words(N);
+    if (c == N) return tile + 16 * N + (g & 15);
+    const int quarter = N >> 2, q = c / quarter, kk = c & (quarter - 1);
+    return tile + ((((kk >> 2) * 64 + q * 16 + (g & 15)) << 2) | (kk & 3));
+}
 
 // gate pre-step on one TLWE word (a-part: isb = false, b-part: isb = true), hom_nand/src/tfhe.rs:27-71
 __device__ __forceinline__ uint32_t gate_linear(int op, uint32_t x0, uint32_t x1, bool isb) {

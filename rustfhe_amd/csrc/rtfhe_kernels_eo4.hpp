@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_eo4(const EoArgs e
     __syncthreads();
     // MODE_EXTRACT: the key switch of the whole batch follows as its own launch (k_key_switch_mm)
     if (live) {
-        uint32_t* o = a.ext + (size_t)g * (N + 1);
-        for (int c = q * (N / 4) + lane0; c < (q + 1) * (N / 4); c += 64) o[c] = accbuf[N + c];
-        if (q == 0 && lane0 == 0) o[N] = accbuf[0];
+        const int ge = a.ext_first + g;      // batch-wide gate number: the sample buffer is laid out for the key switch (ext_slot)
+        for (int c = q * (N / 4) + lane0; c < (q + 1) * (N / 4); c += 64) *ext_slot(a.ext, ge, c, N) = accbuf[N + c];
+        if (q == 0 && lane0 == 0) *ext_slot(a.ext, ge, N, N) = accbuf[0];
         for (int c = q * 64 + lane0; c <= n; c += 256) io.out[c] = 0u;
     }
 }

@@ -16,13 +16,17 @@
 // K order (free, as long as both operands use it): K-step ks = 2 kk + h (kk < N/4, h < 2); lane group q = lane / 16 owns coefficient
 // i = q N/4 + kk; the 16 operand bytes of a lane are t = 4 j + d: level l = 4 h + j, digit value d (d = 0: a zero key row).
 // Key matrix in HBM: [colgroup = col / 16][ks][limb][lane][16 B] -- one 1 KiB dwordx4 load per MFMA operand, contiguous 4 KiB per
-// K-step of a wave.  A wave owns MT = 4 tiles of 16 gates x one column group (16 columns x 4 limbs) x one K-slice: 16 MFMAs per K-step,
-// 64 accumulator registers, key operands of 4 K-steps in flight; K-slices add their parts to the (zeroed) output with wrapping u32
-// atomics (order-free).  The grid is laid out so that all gate groups and slices of a column group share one XCD's L2
-// (blockIdx % 8 == cg % 8 when the column-group count is a multiple of 8: 40 for n = 635).
+// K-step.  A wave owns MT = 4 tiles of 16 gates x one column group (16 columns x 4 limbs) x one K-slice: 16 MFMAs per K-step, 64 accumulator
+// registers; K-slices add their parts to the (zeroed) output with wrapping u32 atomics (order-free).
+// The OTHER operand -- the batch's lvl1 samples -- lies in the order this kernel reads it (ext_slot, rtfhe_kernels.hpp: tiles of 16 gates, the
+// four coefficients a lane needs for two chunks are 16 contiguous bytes, a wave's 64 lanes one contiguous KiB): the extract launch writes it so.
+// Round 5 measured what rows of N + 1 words cost here: every wave-load touched 64 cache lines for 1 KiB, each line re-fetched from the L2 for its
+// other pieces and by each of the 40 column groups -- 13 GB of L2 requests and 2.3 GB from the fabric side per 8,192 gates, the launch waited for
+// those (matrix pipe 41 % busy); tiled: 0.79 -> 0.40 ms per 8,192 gates, 0.115 -> 0.082 ms per 1,024 (profiles/r05/key_switch_mm_ab.log).
 // The one-hot operand of a K-step is a function of ONE byte of a gate's rounded coefficient (four 2-bit digits -> four words with one byte
-// set): it is read from a 256-entry table in LDS (one ds_read_b128) instead of being built with 16 shifts and masks per gate tile and K-step
-// -- with four tiles per wave those ~300 VALU cycles per K-step, not the 16 MFMAs (256 cycles), were what a wave waited for (round 5).
+// set): it is read from a 256-entry table in LDS (one ds_read_b128) instead of being built with 16 shifts and masks per gate tile and K-step.
+// (Building it with v_cvt_pk_u8_f32 -- 8 instructions per operand, no table -- measured 2-4 % slower than the table, whose lookups conflict on
+// banks in 46 % of the LDS cycles without the LDS being what the launch waits for; same log.)
 #pragma once
 
 #include "rtfhe_kernels.hpp"
@@ -30,12 +34,13 @@
 namespace rtfhe {
 
 struct KsMmArgs {
-    const uint32_t* tlwe1;   // [count][N+1]: extracted lvl1 samples a'[0..N), b'
+    const uint32_t* tlwe1;   // extracted lvl1 samples a'[0..N), b' of `count` gates in tiles of 16 (ext_slot, rtfhe_kernels.hpp)
     const uint4* kmat;       // [colgroups][N/2 K-steps][4 limbs][64 lanes] x 16 B
     uint32_t* out;           // row g (plain batch) or row idx_out[g] (netlist wave) of [..][n+1]; ZERO on entry (the extract launch
                              // zeroes it): every K-slice adds its part with a wrapping atomic (order-free in u32)
     int32_t count, n, N, colgroups;
     int32_t splitk;          // K-slices per (gate group, column group): N/4 must be divisible by 4 * splitk
+    int32_t mgroups;         // workgroups along the gates: ceil(count / (64 * KSMM_WAVES))
     // netlist wave (all null for a plain batch): the same validity rule as gate_io -- a gate the bootstrap launch skipped is skipped here
     const int32_t* ops; const int32_t* idx0; const int32_t* idx1; const int32_t* idx_out;
     int32_t num_wires;
@@ -47,7 +52,9 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 // K-step's key operand is fetched ONCE per workgroup -- cooperatively, a chunk of 4 K-steps (16 KiB) at a time into one of two LDS buffers while
 // the other is being multiplied -- and read from LDS by every wave.  (Round 4's one-wave workgroups each streamed the panel themselves: 0.43 GB
 // from the fabric side for an 84 MB operand per 1,024-gate launch, and the launch waited for exactly that; round 5.)
-// grid: x = (mgb * splitk + slice) * colgroups + cg, mgb = group of 64 * KSMM_WAVES gates
+// grid: x = ((slice * ceil(colgroups / 8) + cg / 8) * mgroups + mgb) * 8 + cg % 8, mgb = group of 64 * KSMM_WAVES gates: workgroups go to the
+// XCDs round-robin, so the mgroups workgroups that walk one (column group, slice) panel are neighbours in dispatch order ON ONE XCD -- they start
+// together, keep step (same work each) and the panel comes from HBM once, the others' reads hit that XCD's L2.
 constexpr int KSMM_WAVES = 8;
 constexpr int KSMM_CHUNK = 4;         // K-steps per LDS chunk (= 2 coefficients per lane group)
 template <int KS_T, int KS_BB>
@@ -60,18 +67,12 @@ __global__ __launch_bounds__(64 * KSMM_WAVES, 1) void k_key_switch_mm(const KsMm
     constexpr uint32_t ROUND = 1u << (32 - KS_T * KS_BB - 1);
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = blockIdx.x % a.colgroups, rest = blockIdx.x / a.colgroups;
-    const int slice = rest % a.splitk, mg = (rest / a.splitk) * W + wave;      // this wave's group of 64 gates
+    const int cg8 = (a.colgroups + 7) >> 3, rest = blockIdx.x >> 3, panel = rest / a.mgroups;
+    const int cg = (panel % cg8) * 8 + (blockIdx.x & 7), slice = panel / cg8;
+    if (cg >= a.colgroups) return;                                              // (the column groups padded to whole XCD rounds)
+    const int mg = (rest % a.mgroups) * W + wave;                               // this wave's group of 64 gates
     const int quarter = a.N / 4, ksteps = a.N / 2;
     const int kk_begin = quarter / a.splitk * slice, kk_end = kk_begin + quarter / a.splitk;     // coefficients (per lane group) of this slice
-    const size_t w1 = (size_t)a.N + 1;
-    // the gates whose one-hot rows this lane builds (row r16 of each of the MT tiles); tiles past the batch shadow the last gate
-    const uint32_t* src[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int g = min((mg * MT + mt) * 16 + r16, a.count - 1);
-        src[mt] = a.tlwe1 + (size_t)g * w1 + (size_t)q * quarter;
-    }
     // one-hot operands by digit byte: entry b = { 1 << 8 ((b >> 6) & 3), 1 << 8 ((b >> 4) & 3), 1 << 8 ((b >> 2) & 3), 1 << 8 (b & 3) }
     __shared__ v4i_t onehot[256];
     __shared__ v4i_t kbuf[2][CHUNK_V4];                   // [buffer][K-step of the chunk][limb][lane]
@@ -82,6 +83,15 @@ __global__ __launch_bounds__(64 * KSMM_WAVES, 1) void k_key_switch_mm(const KsMm
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[mt][j] = (v4i_t){0, 0, 0, 0};
+    // The samples lie in tiles of 16 gates (ext_slot, rtfhe_kernels.hpp): the four coefficients kk .. kk + 3 of a tile's 64 (q, gate) rows are
+    // one contiguous KiB, lane-linear -- read through a buffer resource with the tile and the coefficient group in the scalar offset.  A tile past
+    // the batch reads the last one (its rows are never written); the rows past the batch inside the last tile are allocated, whatever they hold.
+    const int ntiles = (a.count + 15) >> 4, tile_bytes = (int)(ext_tile_words(a.N) * 4);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.tlwe1), 0, ntiles * tile_bytes, 0x00020000);
+    int tile_soff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) tile_soff[mt] = __builtin_amdgcn_readfirstlane(min(mg * MT + mt, ntiles - 1) * tile_bytes);
+    const int lane16 = lane * 16;
     // The chunk of K-steps [ks0, ks0 + KC) of this column group's panel is CHUNK_V4 consecutive uint4: thread t stages uint4 t, t + NT, ...
     // through a buffer resource (scalar chunk offset + one lane VGPR + immediates).
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -108,8 +118,10 @@ __global__ __launch_bounds__(64 * KSMM_WAVES, 1) void k_key_switch_mm(const KsMm
         if (c + 1 < nchunks) fetch_chunk(2 * kk2 + KC);   // the next chunk: in flight under this chunk's multiplies
         if ((c & 1) == 0) {                               // gate words of four coefficients at a time (two chunks)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-                aw[mt] = make_uint4(src[mt][kk2], src[mt][kk2 + 1], src[mt][kk2 + 2], src[mt][kk2 + 3]);   // rows of N+1 words: 4-byte aligned only
+            for (int mt = 0; mt < MT; mt++) {
+                const v4u w = __builtin_amdgcn_raw_buffer_load_b128(srsrc, lane16, tile_soff[mt] + __builtin_amdgcn_readfirstlane(kk2 * 256), 0);
+                aw[mt] = make_uint4(w.x, w.y, w.z, w.w);
+            }
         }
         const v4i_t* kb = kbuf[c & 1] + lane;
 #pragma unroll
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(64 * KSMM_WAVES, 1) void k_key_switch_mm(const KsMm
                 row = (size_t)o;
             }
             const uint32_t s = (uint32_t)acc[mt][0][r] + ((uint32_t)acc[mt][1][r] << 8) + ((uint32_t)acc[mt][2][r] << 16) + ((uint32_t)acc[mt][3][r] << 24);
-            const uint32_t bprime = (col == a.n && slice == 0) ? a.tlwe1[(size_t)g * w1 + a.N] : 0u;
+            const uint32_t bprime = (col == a.n && slice == 0) ? a.tlwe1[(size_t)(g >> 4) * ext_tile_words(a.N) + 16 * a.N + (g & 15)] : 0u;
             atomicAdd(a.out + row * ((size_t)a.n + 1) + col, bprime - s);
         }
     }

@@ -318,9 +318,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_pair(const Ntt
     __syncthreads();
     if (a.mode == MODE_EXTRACT) {      // the key switch of the whole batch follows as its own launch (k_key_switch_mm)
         if (live) {
-            uint32_t* o = a.ext + (size_t)g * (N + 1);
-            for (int c = side * (N / 2) + lane; c < (side + 1) * (N / 2); c += 64) o[c] = accbuf[N + c];
-            if (side == 0 && lane == 0) o[N] = accbuf[0];
+            const int ge = a.ext_first + g;      // batch-wide gate number: the sample buffer is laid out for the key switch (ext_slot)
+            for (int c = side * (N / 2) + lane; c < (side + 1) * (N / 2); c += 64) *ext_slot(a.ext, ge, c, N) = accbuf[N + c];
+            if (side == 0 && lane == 0) *ext_slot(a.ext, ge, N, N) = accbuf[0];
             for (int c = side * 64 + lane; c <= n; c += 128) io.out[c] = 0u;
         }
         return;

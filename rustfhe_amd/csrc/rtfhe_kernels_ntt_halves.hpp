@@ -259,9 +259,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_ntt_halves(const N
     __syncthreads();
     if (a.mode == MODE_EXTRACT) {      // the key switch of the whole batch follows as its own launch (k_key_switch_mm)
         if (live) {
-            uint32_t* o = a.ext + (size_t)g * (N + 1);
-            for (int c = H * (N / 2) + lane0; c < (H + 1) * (N / 2); c += 64) o[c] = accbuf[N + c];
-            if (H == 0 && lane0 == 0) o[N] = accbuf[0];
+            const int ge = a.ext_first + g;      // batch-wide gate number: the sample buffer is laid out for the key switch (ext_slot)
+            for (int c = H * (N / 2) + lane0; c < (H + 1) * (N / 2); c += 64) *ext_slot(a.ext, ge, c, N) = accbuf[N + c];
+            if (H == 0 && lane0 == 0) *ext_slot(a.ext, ge, N, N) = accbuf[0];
             for (int c = H * 64 + lane0; c <= n; c += 128) io.out[c] = 0u;
         }
         return;

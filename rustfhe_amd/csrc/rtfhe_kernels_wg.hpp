@@ -269,9 +269,9 @@ __global__ __launch_bounds__(512, 1) void k_bootstrap_wg(const BootstrapArgs a) 
     }
     __syncthreads();
     if (a.mode == MODE_EXTRACT) {      // the key switch of the whole batch follows as its own launch (k_key_switch_mm)
-        uint32_t* o = a.ext + (size_t)g * (N + 1);
-        for (int c = tid; c < N; c += 64 * NW) o[c] = accbuf[N + c];
-        if (tid == 0) o[N] = bprime;
+        const int ge = a.ext_first + g;      // batch-wide gate number: the sample buffer is laid out for the key switch (ext_slot)
+        for (int c = tid; c < N; c += 64 * NW) *ext_slot(a.ext, ge, c, N) = accbuf[N + c];
+        if (tid == 0) *ext_slot(a.ext, ge, N, N) = bprime;
         for (int c = tid; c <= n; c += 64 * NW) io.out[c] = 0u;
         return;
     }

@@ -2,6 +2,7 @@
 // whole batch, as one i8 contraction), the key permutes, and the reference's transforms at any power of two (FFT plans).  The parity tests use
 // these to localise a mismatch; they run the same device functions as the fused kernels.
 #include "rtfhe_host.hpp"
+#include <cmath>
 
 #include "rtfhe_kernels_ksmm.hpp"
 #include "rtfhe_kernels_anyn.hpp"
@@ -105,10 +106,19 @@ int launch_ksmat_build(rtfhe_ctx* ctx, const uint32_t* d_raw, int colgroups, hip
 int launch_key_switch_mm(rtfhe_ctx* ctx, const BootstrapArgs& a, const uint32_t* samples, hipStream_t s) {
     const int per_block = 16 * KSMM_MT * KSMM_WAVES;      // gates of a workgroup: KSMM_WAVES waves x 4 tiles of 16
     const int colgroups = (ctx->p.n + 1 + 15) / 16, mgroups = (a.count + per_block - 1) / per_block;
-    // K-slices: enough workgroups to give every CU two or three (the slices of one launch add into the zeroed output); a slice is a whole
-    // number of LDS chunks of two coefficients per lane group
+    // K-slices (the slices of one launch add into the zeroed output; a slice is a whole number of LDS chunk pairs: four coefficients per lane
+    // group).  Two workgroups fit a CU and share its matrix pipe, so what a launch costs is the LARGEST number of workgroups a CU ends up
+    // with: take the fewest slices whose workgroup count fills whole rounds of the CUs (640 workgroups on 256 CUs leave half the chip idle
+    // for the third of three rounds; 1,280 are five full ones).
     int splitk = 1;
-    while (splitk < 16 && (size_t)mgroups * colgroups * splitk < (size_t)5 * ctx->num_cus / 2 && (ctx->p.N / 4) % (4 * splitk) == 0) splitk *= 2;
+    {
+        double best = 0;
+        for (int sk = 1; sk <= 32 && (ctx->p.N / 4) % (4 * sk) == 0; sk *= 2) {
+            const double rounds = (double)mgroups * colgroups * sk / ctx->num_cus;
+            const double eff = rounds / std::ceil(rounds) * std::min(1.0, rounds / 2.0);
+            if (eff > best + 0.03) { best = eff; splitk = sk; }
+        }
+    }
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // (no bracketing inside rtfhe_circuit_create's capture: a recorded event would become a graph node and rtfhe_timer_end would then ask
     // a never-recorded event for its time; and a timer that is never ended stops taking events at 4096 pairs)
@@ -118,9 +128,16 @@ int launch_key_switch_mm(rtfhe_ctx* ctx, const BootstrapArgs& a, const uint32_t*
         ctx->ks_events_used += 2;
         HIPCHECK(ctx, hipEventRecord(ev_a, s));
     }
-    KsMmArgs k{samples, ctx->d_ksmat, a.out, a.count, ctx->p.n, ctx->p.N, colgroups, splitk, a.ops, a.idx0, a.idx1, a.idx_out, a.num_wires};
-    hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mgroups * colgroups * splitk), dim3(64 * KSMM_WAVES), 0, s, k);
-    HIPCHECK(ctx, hipGetLastError());
+    // the kernel addresses a launch's samples (tiles of 16 gates, rtfhe::ext_slot) with 32-bit byte offsets: at most 2 GiB of them per launch
+    const size_t w1 = (size_t)ctx->p.N + 1, seg_max = ((size_t)1 << 31) / (w1 * 4) / per_block * per_block;
+    for (size_t off = 0; off < (size_t)a.count; off += seg_max) {
+        const size_t cnt = std::min(seg_max, (size_t)a.count - off);
+        const int mg = (int)((cnt + per_block - 1) / per_block);
+        KsMmArgs k{samples + off * w1, ctx->d_ksmat, a.idx_out ? a.out : a.out + off * ((size_t)ctx->p.n + 1), (int32_t)cnt, ctx->p.n, ctx->p.N, colgroups, splitk, mg,
+                   a.ops ? a.ops + off : nullptr, a.idx0 ? a.idx0 + off : nullptr, a.idx1 ? a.idx1 + off : nullptr, a.idx_out ? a.idx_out + off : nullptr, a.num_wires};
+        hipLaunchKernelGGL((k_key_switch_mm<8, 2>), dim3(mg * ((colgroups + 7) / 8 * 8) * splitk), dim3(64 * KSMM_WAVES), 0, s, k);
+        HIPCHECK(ctx, hipGetLastError());
+    }
     if (ev_b) HIPCHECK(ctx, hipEventRecord(ev_b, s));
     ctx->launches++;
     return 0;

@@ -12,6 +12,7 @@
 #   circuit          scripts/bench_circuit.py (the adder netlists)
 #   profile          rocprofv3 kernel trace + PMC passes of the headline (scripts/profile_gpu.sh r05)
 #   profile2048      counters of the N = 2048 kernel (scripts/profile_n2048.sh eo)
+#   pmc:<kernel>:<gates>[:N[:matrix|plain[:fft|ntt]]]   counters of one kernel family on a batch (scripts/profile_kernel.sh)
 #   ab:<N>:<gates>:<rounds>:<lib>[,<lib>...]   same-process A/B of builds under build/ab/ ("shipped" = rustfhe_amd/librtfhe_hip.so)
 #   ubench:<name>    scripts/ubench/<name> (a prebuilt micro-benchmark binary)
 #   keycache         FETCH_SIZE / time of a tail launch alone and behind a full round (scripts/profile_keycache.sh)
@@ -27,7 +28,7 @@ O=gpurun_out/$TAG; mkdir -p $O
 FAILED=0
 run() { local name=$1; shift; echo "== $name: $*"; "$@"; local rc=$?; echo "== $name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then exit $rc; fi; [ $rc -eq 0 ] || FAILED=$rc; }
 for step in "$@"; do
-  IFS=: read -r kind a1 a2 a3 a4 <<< "$step"
+  IFS=: read -r kind a1 a2 a3 a4 a5 <<< "$step"
   case $kind in
     tests)   run tests bash -c "timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=\$?; tail -3 $O/pytest_gpu.log; exit \$rc" ;;
     smoke)   run smoke bash -c "timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; rc=\$?; tail -2 $O/smoke.log; exit \$rc" ;;
@@ -42,6 +43,7 @@ for step in "$@"; do
     circuit) run circuit bash -c "timeout -k 10 300 python scripts/bench_circuit.py > $O/bench_circuit.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/bench_circuit.log | tail -12; exit \$rc" ;;
     profile) run profile bash -c "bash scripts/profile_gpu.sh r05 > $O/profile.log 2>&1; rc=\$?; tail -3 $O/profile.log; cp -r gpurun_out/profiles_r05 $O/ 2>/dev/null; exit \$rc" ;;
     profile2048) run profile2048 bash -c "bash scripts/profile_n2048.sh ${a1:-eo} > $O/profile_n2048.log 2>&1; rc=\$?; tail -3 $O/profile_n2048.log; cp gpurun_out/profiles_n2048/pmc_n2048_${a1:-eo}.json $O/ 2>/dev/null; exit \$rc" ;;
+    pmc)     run "pmc $a1" env RTFHE_BACKEND=${a5:-fft} bash -c "bash scripts/profile_kernel.sh $a1 $a2 ${a3:-1024} $a4 > $O/pmc_$a1.log 2>&1; rc=\$?; tail -60 $O/pmc_$a1.log; cp gpurun_out/pmc_kernel/pmc_${a1}_N${a3:-1024}_g$a2.json $O/ 2>/dev/null; exit \$rc" ;;
     ab)      libs=$(echo "$a4" | tr ',' ' ' | sed -E 's#(^| )shipped#\1rustfhe_amd/librtfhe_hip.so#g; s#(^| )([A-Za-z0-9_]+)( |$)#\1build/ab/\2.so\3#g; s#(^| )([A-Za-z0-9_]+)( |$)#\1build/ab/\2.so\3#g')
              first=$(echo $libs | cut -d" " -f1)
              run "ab N=$a1 gates=$a2" env RTFHE_N=$a1 RTFHE_LIB=$first bash -c "timeout -k 10 400 python scripts/ab_libs.py $a2 $a3 $libs 2>&1 | grep -v amdgpu.ids | tee -a $O/ab_N${a1}_g${a2}.log" ;;
