@@ -15,6 +15,7 @@
 #   pmc:<kernel>:<gates>[:N[:matrix|plain[:fft|ntt]]]   counters of one kernel family on a batch (scripts/profile_kernel.sh)
 #   ab:<N>:<gates>:<rounds>:<lib>[,<lib>...]   same-process A/B of builds under build/ab/ ("shipped" = rustfhe_amd/librtfhe_hip.so)
 #   ubench:<name>    scripts/ubench/<name> (a prebuilt micro-benchmark binary)
+#   clock:<name>     the shader clock scripts/ubench/<name>'s kernels ran at, launch by launch (scripts/kernel_clock.sh)
 #   keycache         FETCH_SIZE / time of a tail launch alone and behind a full round (scripts/profile_keycache.sh)
 #   soak             scripts/soak.py
 #   py:<script>[:args,comma,separated]        any python script of scripts/
@@ -48,6 +49,7 @@ for step in "$@"; do
              first=$(echo $libs | cut -d" " -f1)
              run "ab N=$a1 gates=$a2" env RTFHE_N=$a1 RTFHE_LIB=$first bash -c "timeout -k 10 400 python scripts/ab_libs.py $a2 $a3 $libs 2>&1 | grep -v amdgpu.ids | tee -a $O/ab_N${a1}_g${a2}.log" ;;
     ubench)  run "ubench $a1" bash -c "timeout -k 10 300 scripts/ubench/$a1 > $O/ubench_$a1.log 2>&1; rc=\$?; cat $O/ubench_$a1.log; exit \$rc" ;;
+    clock)   run "clock $a1" bash -c "bash scripts/kernel_clock.sh $REPO/scripts/ubench/$a1 > $O/clock_$a1.log 2>&1; rc=\$?; tail -70 $O/clock_$a1.log; cp gpurun_out/clock/$a1.json $O/clock_$a1.json 2>/dev/null; exit \$rc" ;;
     keycache) run keycache bash -c "bash scripts/profile_keycache.sh > $O/keycache.log 2>&1; rc=\$?; tail -40 $O/keycache.log; cp gpurun_out/keycache/keycache.json $O/ 2>/dev/null; exit \$rc" ;;
     soak)    run soak bash -c "timeout -k 10 600 python scripts/soak.py > $O/soak.log 2>&1; rc=\$?; tail -5 $O/soak.log; exit \$rc" ;;
     py)      args=$(echo "$a2" | tr ',' ' '); run "py $a1" bash -c "timeout -k 10 500 python scripts/$a1 $args > $O/$(basename $a1 .py).log 2>&1; rc=\$?; grep -v amdgpu.ids $O/$(basename $a1 .py).log | tail -40; exit \$rc" ;;

@@ -118,5 +118,10 @@ int main() {
     // 157 salu (profiles/r05/pmc_n2048_eo.json / 2).  Two mixes that bracket it:
     if (run<39, 5, 3, 4, 1, 2, 104, 2>("k_bootstrap_eo's round-5 mix, lower bracket", out, gsrc, cus)) return 1;
     if (run<39, 6, 4, 5, 2, 2, 104, 2>("k_bootstrap_eo's round-5 mix, upper bracket", out, gsrc, cus)) return 1;
+    // k_bootstrap_ntt_pair (exact-integer backend, N = 1024) per wave and step (profiles/r05/pmc_k_bootstrap_ntt_N1024_g1024.json / 2): 3,324 FP64,
+    // 401 integer VALU, 312 LDS (16-byte accesses), 48 vmem, 51 salu.  Two mixes that bracket it (85 units of 39 FP64 = 3,315):
+    if (run<39, 4, 1, 2, 0, 0, 85, 2, true>("k_bootstrap_ntt_pair's mix, lower bracket", out, gsrc, cus)) return 1;
+    if (run<39, 5, 2, 2, 1, 1, 85, 2, true>("k_bootstrap_ntt_pair's mix, upper bracket", out, gsrc, cus)) return 1;
+    if (run<39, 0, 0, 0, 0, 0, 85>("... its FP64 instructions alone", out, gsrc, cus)) return 1;
     return 0;
 }
