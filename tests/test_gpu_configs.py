@@ -451,6 +451,34 @@ def test_batch_key_switch_on_the_matrix_pipe_equals_the_fused_kernel(orc, monkey
         fused.close(); split.close()
 
 
+def test_batch_key_switch_sample_tiles_at_every_ragged_count(orc, monkeypatch):
+    """The lvl1 samples travel from the extract launch to k_key_switch_mm in tiles of 16 gates (ext_slot, rtfhe_kernels.hpp): counts below, at and
+    just past a tile and a workgroup of the key switch (512 gates), a remainder behind whole rounds, and segments of one batch that start inside
+    the sample buffer (ext_first) must all give the fused kernel's torus words."""
+    import rustfhe_amd as R
+    n = 60
+    P = orc.Params(n=n)
+    K = orc.Keys(P, 77)
+    p = R.Params(n=n)
+    monkeypatch.setenv("RTFHE_KS_MM_MIN", "0")
+    fused = R.Engine(p, 0)
+    monkeypatch.delenv("RTFHE_KS_MM_MIN")
+    split = R.Engine(p, 0)
+    try:
+        for e in (fused, split):
+            e.load_bk_torus(K.bk_t)
+            e.load_ksk(K.ksk)
+        rng = np.random.default_rng(5)
+        G = 2048 + 1024 + 17
+        c0 = rng.integers(0, 2 ** 32, (G, n + 1), dtype=np.uint64).astype(np.uint32)
+        c1 = rng.integers(0, 2 ** 32, (G, n + 1), dtype=np.uint64).astype(np.uint32)
+        for k in (1, 15, 16, 17, 100, 511, 512, 513, 1025, 1040, 1024 + 300, G):
+            a, b = fused.gate_batch(R.OR, c0[:k], c1[:k]), split.gate_batch(R.OR, c0[:k], c1[:k])
+            assert np.array_equal(a, b), k
+    finally:
+        fused.close(); split.close()
+
+
 def test_batch_key_switch_split_path_n2048(monkeypatch):
     """N = 2048 (config 5): both backends, whole round + remainder, fused (RTFHE_KS_MM_MIN=0) against split, word for word."""
     import rustfhe_amd as R
