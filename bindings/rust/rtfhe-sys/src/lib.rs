@@ -27,6 +27,7 @@ pub const RTFHE_ANDNY: c_int = 6;
 
 pub const RTFHE_BACKEND_FFT64_MIRROR: c_int = 0;
 pub const RTFHE_BACKEND_NTT_EXACT: c_int = 1;
+pub const RTFHE_BACKEND_FFT_SPLIT_EXACT: c_int = 2;
 
 pub const RTFHE_OK: c_int = 0;
 pub const RTFHE_ERR_INVALID: c_int = -1;

@@ -91,9 +91,12 @@ typedef enum {
 typedef enum {
     RTFHE_BACKEND_FFT64_MIRROR = 0,  /* default: FP64 transform mirroring the reference's spqlios operation for operation;
                                         outputs bit-identical to the reference CPU path */
-    RTFHE_BACKEND_NTT_EXACT = 1      /* exact negacyclic NTT mod P = 2^50 - 16383 (N = 1024 and 2048): reference semantics of the exact
+    RTFHE_BACKEND_NTT_EXACT = 1,     /* exact negacyclic NTT mod P = 2^50 - 16383 (N = 1024 and 2048): reference semantics of the exact
                                         Polynomial::cross (utils/src/math.rs:238-257); bit-identical to an exact-integer
                                         evaluation, decrypt-level parity with the reference's FFT path */
+    RTFHE_BACKEND_FFT_SPLIT_EXACT = 2 /* the same exact products (bit-identical to RTFHE_BACKEND_NTT_EXACT) through an FMA-contracted FP64 FFT:
+                                        the key split into signed 16-bit halves, each half-product rounded to the nearest integer (error proven
+                                        < 2^-8 for every input) and recombined mod 2^32; N = 1024; needs the key in torus form */
 } rtfhe_backend;
 
 /* ---- context ---- */

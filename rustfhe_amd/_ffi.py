@@ -30,7 +30,7 @@ class Params(C.Structure):
 
 
 NAND, AND, OR, XOR, NOT, COPY, ANDNY = range(7)
-BACKEND_FFT64_MIRROR, BACKEND_NTT_EXACT = 0, 1
+BACKEND_FFT64_MIRROR, BACKEND_NTT_EXACT, BACKEND_FFT_SPLIT_EXACT = 0, 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
 _SIGNATURES = {

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtfhe_hip.so")
 OBJ = os.path.join(HERE, "..", "build", "obj")
 # device code lives in the .hip units (every kernel is instantiated in exactly one of them); the .cpp units are host-only
-HIP_SOURCES = ["rtfhe_dispatch_fft.hip", "rtfhe_dispatch_ntt.hip", "rtfhe_stages.hip", "rtfhe_context.hip", "rtfhe_twiddles.hip",
+HIP_SOURCES = ["rtfhe_dispatch_fft.hip", "rtfhe_dispatch_ntt.hip", "rtfhe_dispatch_xfft.hip", "rtfhe_stages.hip", "rtfhe_context.hip", "rtfhe_twiddles.hip",
                "rtfhe_batch.hip", "rtfhe_circuit.hip", "rtfhe_multi.hip"]
 CPP_SOURCES = ["rtfhe_keygen.cpp", "rtfhe_wire.cpp", "rtfhe_spqlios.cpp"]
 SOURCES = HIP_SOURCES + CPP_SOURCES

@@ -7,6 +7,12 @@ using namespace rtfhe_host;
 
 namespace rtfhe_host {
 
+int backend_prepare(rtfhe_ctx* ctx) {
+    if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) return ntt_prepare(ctx);
+    if (ctx->backend == RTFHE_BACKEND_FFT_SPLIT_EXACT) return xfft_prepare(ctx);
+    return 0;
+}
+
 // lvl1 sample buffer of the split path for stream s: sized outside launches (hipMalloc is not allowed inside a stream capture)
 int ensure_tlwe1(rtfhe_ctx* ctx, rtfhe_ctx::Tlwe1& b, size_t gates) {
     if (b.cap >= gates) return 0;
@@ -55,6 +61,10 @@ int launch_bootstrap(rtfhe_ctx* ctx, int op, int mode, int steps, const void* d_
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
         if (int rc = ntt_prepare(ctx)) return rc;
         return launch_bootstrap_ntt(ctx, a, s);
+    }
+    if (ctx->backend == RTFHE_BACKEND_FFT_SPLIT_EXACT) {
+        if (int rc = xfft_prepare(ctx)) return rc;
+        return launch_bootstrap_xfft(ctx, a, s);
     }
     return launch_bootstrap_fft(ctx, a, s);
 }

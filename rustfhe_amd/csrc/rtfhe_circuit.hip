@@ -47,8 +47,7 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
     if (!ctx->has_bk || !ctx->has_ksk) return fail(ctx, RTFHE_ERR_STATE, "keys not loaded");
     if (!gpu_accessible(ctx, d_ops) || !gpu_accessible(ctx, d_idx0) || !gpu_accessible(ctx, d_idx1) || !gpu_accessible(ctx, d_idx_out) || !gpu_accessible(ctx, d_wires))
         return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_circuit_create needs device pointers (got memory the GPU cannot address)");
-    if (ctx->backend == RTFHE_BACKEND_NTT_EXACT)
-        if (int rc = ntt_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
+    if (int rc = backend_prepare(ctx)) return rc;          // nothing but kernel launches may happen inside the capture
     for (int32_t w = 0; w < num_waves; w++)                // ... so the key layouts the waves' dispatches read are built now
         if (int rc = ensure_bk_layouts(ctx, (size_t)(wave_offsets[w + 1] - wave_offsets[w]), MODE_GATE)) return rc;
     rtfhe_ctx::Tlwe1 cbuf;                                 // ... so the circuit's own sample buffer (split path) is allocated now

@@ -42,7 +42,7 @@ int transform_bk_from_torus(rtfhe_ctx* ctx) {
 
 // a new key (or new tables under a torus-form key): whatever was derived from the old spectra is stale
 void key_changed(rtfhe_ctx* ctx) {
-    ctx->ebk_valid = false; ctx->p4bk_valid = false; ctx->ntt_ready = false;
+    ctx->ebk_valid = false; ctx->p4bk_valid = false; ctx->ntt_ready = false; ctx->xfft_ready = false;
 }
 
 }  // namespace
@@ -191,6 +191,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
     }
     if (!rc) rc = prime_fft_kernels(ctx);
     if (!rc) rc = prime_ntt_kernels(ctx);
+    if (!rc) rc = prime_xfft_kernels(ctx);
     if (!rc) rc = upload_twiddles(ctx);
     if (!rc && (hipMalloc((void**)&ctx->d_fault, 4) != hipSuccess || hipMemset(ctx->d_fault, 0, 4) != hipSuccess))
         rc = fail(ctx, RTFHE_ERR_HIP, "hipMalloc failed");
@@ -240,6 +241,7 @@ int rtfhe_ctx_memory_bytes(const rtfhe_ctx* ctx, int d, size_t* bytes) {
     if (c->d_p4bk) b += spectra;
     if (c->d_bk_torus) b += bk_word_count(c->p) * 4;
     if (c->d_ntt_bk) b += bk_word_count(c->p) * sizeof(double);
+    if (c->d_xbk) b += 2 * spectra;
     if (c->d_ksk) b += c->ksk_bytes;
     if (c->d_ksmat) b += c->ksmat_bytes;
     for (const auto& kv : c->tlwe1) b += kv.second.cap * ((size_t)c->p.N + 1) * 4;
@@ -281,6 +283,8 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_bk_torus) (void)hipFree(ctx->d_bk_torus);
     if (ctx->d_ntt_bk) (void)hipFree(ctx->d_ntt_bk);
     if (ctx->d_ntt_tw) (void)hipFree(ctx->d_ntt_tw);
+    if (ctx->d_xbk) (void)hipFree(ctx->d_xbk);
+    if (ctx->d_xtw) (void)hipFree(ctx->d_xtw);
     if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
     if (ctx->d_ksmat) (void)hipFree(ctx->d_ksmat);
     for (auto& kv : ctx->tlwe1) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -299,7 +303,9 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
 
 int rtfhe_set_backend(rtfhe_ctx* ctx, int backend) {
     if (int rc = use(ctx)) return rc;
-    if (backend != RTFHE_BACKEND_FFT64_MIRROR && backend != RTFHE_BACKEND_NTT_EXACT) return fail(ctx, RTFHE_ERR_INVALID, "unknown backend");
+    if (backend != RTFHE_BACKEND_FFT64_MIRROR && backend != RTFHE_BACKEND_NTT_EXACT && backend != RTFHE_BACKEND_FFT_SPLIT_EXACT)
+        return fail(ctx, RTFHE_ERR_INVALID, "unknown backend");
+    if (backend == RTFHE_BACKEND_FFT_SPLIT_EXACT && ctx->logn != 10) return fail(ctx, RTFHE_ERR_INVALID, "the split-FFT exact backend is built for N = 1024");
     ctx->backend = backend;
     for (rtfhe_ctx* peer : ctx->peers) peer->backend = backend;
     return 0;

@@ -1,0 +1,140 @@
+// rtfhe_dispatch_xfft.hip -- the split-FFT exact backend (rtfhe_xfft.hpp, N = 1024): host tables, the split key spectra, kernel shapes per batch.
+#include "rtfhe_host.hpp"
+
+#include <cmath>
+
+#include "rtfhe_kernels_xfft.hpp"
+
+using namespace rtfhe;
+using namespace rtfhe_host;
+
+namespace {
+
+typedef xfft::XTw XTw;
+
+cplx unit(long double angle) { return make_double2((double)cosl(angle), (double)sinl(angle)); }
+
+// The device table (layout: XTw).  Angles are formed in long double and rounded once: an entry is within 1 ulp of the true value, which is all
+// the error analysis assumes (scripts/xfft/model.py) -- no bit of this table has to match anything.
+//   forward, stage s (1..9), block B:  w = exp(i theta_{s,B} / 2),  theta_{1,0} = pi/2,  theta_{s+1,2B} = theta_{s,B}/2,  theta_{s+1,2B+1} = theta_{s,B}/2 + pi
+//   inverse, stage t (1..9), q < 2^(t-1):  w = exp(-2 pi i q / 2^t)
+//   untwist, j < 512:  exp(-i (pi/2) j / 512) / 512
+std::vector<cplx> xfft_device_table() {
+    const long double PI = 3.141592653589793238462643383279502884L;
+    constexpr int n = 512, LOG = 9;
+    std::vector<std::vector<long double>> theta(LOG + 2);
+    theta[1] = {PI / 2};
+    for (int s = 1; s <= LOG; s++) {
+        theta[s + 1].resize(theta[s].size() * 2);
+        for (size_t B = 0; B < theta[s].size(); B++) { theta[s + 1][2 * B] = theta[s][B] / 2; theta[s + 1][2 * B + 1] = theta[s][B] / 2 + PI; }
+    }
+    auto fw = [&](int s, int B) { return unit(theta[s][B] / 2); };
+    auto iw = [&](int t, int q) { return unit(-2 * PI * (long double)q / (long double)(1 << t)); };
+    std::vector<cplx> tb(XTw::TOTAL, make_double2(0.0, 0.0));
+    // entry e of a forward pass whose first stage is s0: e = 0: (s0, c), 1 + q: (s0 + 1, 2 c + q), 3 + q: (s0 + 2, 4 c + q); c = the block of stage s0
+    auto fwd_entries = [&](int base, int s0, int classes) {
+        for (int c = 0; c < classes; c++) {
+            tb[base + 0 * classes + c] = fw(s0, c);
+            for (int q = 0; q < 2; q++) tb[base + (1 + q) * classes + c] = fw(s0 + 1, 2 * c + q);
+            for (int q = 0; q < 4; q++) tb[base + (3 + q) * classes + c] = fw(s0 + 2, 4 * c + q);
+        }
+    };
+    fwd_entries(XTw::F1, 1, 1);
+    fwd_entries(XTw::F2, 4, 8);
+    fwd_entries(XTw::F3, 7, 64);
+    // entry e of an inverse pass whose first stage is t0 (half-size h0 = 2^(t0-1)): lane class r < h0; e = 0: (t0, r), 1 + q: (t0 + 1, r + h0 q), 3 + q: (t0 + 2, r + h0 q)
+    auto inv_entries = [&](int base, int t0, int classes) {
+        for (int r = 0; r < classes; r++) {
+            tb[base + 0 * classes + r] = iw(t0, r);
+            for (int q = 0; q < 2; q++) tb[base + (1 + q) * classes + r] = iw(t0 + 1, r + classes * q);
+            for (int q = 0; q < 4; q++) tb[base + (3 + q) * classes + r] = iw(t0 + 2, r + classes * q);
+        }
+    };
+    inv_entries(XTw::I2, 4, 8);
+    inv_entries(XTw::I3, 7, 64);
+    for (int j = 0; j < n; j++) {
+        const cplx u = unit(-(PI / 2) * (long double)j / (long double)n);
+        tb[XTw::UT + j] = make_double2(u.x / n, u.y / n);      // [m][lane] with j = lane + 64 m
+    }
+    return tb;
+}
+
+template <int GATES>
+int launch_xpair_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_xpair<3, 6, 8, 2, KSQ, GATES>;
+    const size_t lds = XPairLds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    XBootstrapArgs a{b, ctx->d_xtw, ctx->d_xbk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(128 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
+// whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU (as the other two-waves-per-gate kernels)
+int launch_xpair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_xpair);
+    const size_t out_words = mode_out_words(a, 1024);
+    const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
+    const size_t full = count / round * round, rem = count - full;
+    if (full)
+        if (int rc = launch_xpair_g<4>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
+    if (!rem) return 0;
+    const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
+    if (rem <= cus) return launch_xpair_g<1>(ctx, tail, s);
+    if (rem <= 2 * cus) return launch_xpair_g<2>(ctx, tail, s);
+    if (rem <= 3 * cus) return launch_xpair_g<3>(ctx, tail, s);
+    return launch_xpair_g<4>(ctx, tail, s);
+}
+
+}  // namespace
+
+namespace rtfhe_host {
+
+int xfft_prepare(rtfhe_ctx* ctx) {
+    if (ctx->xfft_ready) return 0;
+    if (ctx->logn != 10) return fail(ctx, RTFHE_ERR_INVALID, "the split-FFT exact backend is built for N = 1024");
+    if (!ctx->d_bk_torus) return fail(ctx, RTFHE_ERR_STATE, "the split-FFT exact backend needs the bootstrapping key in torus form (rtfhe_load_bk_torus)");
+    if (!ctx->d_xtw) {
+        const std::vector<cplx> t = xfft_device_table();
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_xtw, t.size() * sizeof(cplx)));
+        HIPCHECK(ctx, hipMemcpy(ctx->d_xtw, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    }
+    const size_t polys = bk_word_count(ctx->p) / ctx->p.N;
+    if (!ctx->d_xbk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_xbk, 2 * bk_cplx_count(ctx->p) * sizeof(cplx)));
+    constexpr int W = 4;
+    int grid = (int)((polys + W - 1) / W); if (grid > 2048) grid = 2048;
+    XBkArgs a{ctx->d_xtw, ctx->d_bk_torus, ctx->d_xbk, (int32_t)polys, 2 * ctx->p.l};
+    const size_t lds = (size_t)XTw::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);
+    if (int rc = allow_lds(ctx, k_xbk_build<W>, lds)) return rc;
+    hipLaunchKernelGGL(k_xbk_build<W>, dim3(grid), dim3(64 * W), lds, ctx->stream, a);
+    HIPCHECK(ctx, hipGetLastError());
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->xfft_ready = true;
+    return 0;
+}
+
+int launch_bootstrap_xfft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return launch_xpair(ctx, a, s); }
+
+// external product of `count` TRLWE samples with bk[idx[g]] on this backend (stage-level entry point)
+int launch_extprod_xfft(rtfhe_ctx* ctx, const int32_t* d_idx, const uint32_t* d_in, uint32_t* d_out, int32_t count, hipStream_t s) {
+    constexpr int W = 2;
+    XExtProdArgs a{ctx->d_xtw, ctx->d_xbk, d_idx, d_in, d_out, count};
+    const size_t lds = (size_t)XTw::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);
+    if (int rc = allow_lds(ctx, k_external_product_xfft<3, 6, W>, lds)) return rc;
+    hipLaunchKernelGGL((k_external_product_xfft<3, 6, W>), dim3((count + W - 1) / W), dim3(64 * W), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int prime_xfft_kernels(rtfhe_ctx* ctx) {
+    if (ctx->logn != 10) return 0;
+    const int npad = (ctx->p.n + 1 + 63) / 64 * 64;
+    if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 4>, XPairLds::bytes(4, npad))) return rc;
+    if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 3>, XPairLds::bytes(3, npad))) return rc;
+    if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 2>, XPairLds::bytes(2, npad))) return rc;
+    if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 1>, XPairLds::bytes(1, npad))) return rc;
+    return 0;
+}
+
+}  // namespace rtfhe_host

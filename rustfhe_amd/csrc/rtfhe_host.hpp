@@ -3,6 +3,7 @@
 //   rtfhe_twiddles.hip       host twiddle tables (the reference's builders restated) and the per-kernel device tables
 //   rtfhe_dispatch_fft.hip   the FP64 mirror backend's bootstrap kernels: which kernel shape a batch runs on
 //   rtfhe_dispatch_ntt.hip   the exact-integer NTT backend: host tables, key transform, kernel shapes
+//   rtfhe_dispatch_xfft.hip  the split-FFT exact backend (exact products through an FMA-contracted FP64 FFT, N = 1024)
 //   rtfhe_stages.hip         stage-level kernels and entry points (transforms, external product, key switch, key permutes), FFT plans at any N
 //   rtfhe_batch.hip          batches of gates: the backend switch, split path, host-pointer and device-pointer batches, MUX, timers
 //   rtfhe_circuit.hip        levelised netlists: one wave per call, or all waves recorded into a HIP graph
@@ -67,6 +68,9 @@ struct rtfhe_ctx {
     double* d_ntt_bk = nullptr;
     double* d_ntt_tw = nullptr;
     bool ntt_ready = false;
+    rtfhe::cplx* d_xbk = nullptr;     // split-FFT exact backend: the key as two 16-bit halves, each as spectra (2 x the canonical size)
+    rtfhe::cplx* d_xtw = nullptr;
+    bool xfft_ready = false;
     uint32_t* d_ksk = nullptr;
     int ksw = 0;
     uint4* d_ksmat = nullptr;         // the key-switching key as signed byte limbs in i8-MFMA operand order (rtfhe_kernels_ksmm.hpp)
@@ -170,6 +174,14 @@ int prime_ntt_kernels(rtfhe_ctx* ctx);
 int ntt_prepare(rtfhe_ctx* ctx);                                          // tables + NTT-domain key on first use
 int launch_bootstrap_ntt(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s);
 int launch_extprod_ntt(rtfhe_ctx* ctx, const int32_t* d_idx, const uint32_t* d_in, uint32_t* d_out, int32_t count, hipStream_t s);
+
+// ---- split-FFT exact backend (rtfhe_dispatch_xfft.hip) ----
+int prime_xfft_kernels(rtfhe_ctx* ctx);
+int xfft_prepare(rtfhe_ctx* ctx);                                         // table + split key spectra on first use
+int launch_bootstrap_xfft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s);
+int launch_extprod_xfft(rtfhe_ctx* ctx, const int32_t* d_idx, const uint32_t* d_in, uint32_t* d_out, int32_t count, hipStream_t s);
+// tables / derived keys of whichever exact backend is selected (no-op on the mirror): allocates and synchronises, so outside stream captures only
+int backend_prepare(rtfhe_ctx* ctx);
 
 // ---- stage kernels (rtfhe_stages.hip) ----
 int launch_fft(rtfhe_ctx* ctx, bool forward, rtfhe::FftArgs a, hipStream_t s);

@@ -165,6 +165,9 @@ int rtfhe_external_product_batch(rtfhe_ctx* ctx, const int32_t* bk_index, const 
     if (ctx->backend == RTFHE_BACKEND_NTT_EXACT) {
         if ((rc = ntt_prepare(ctx))) return rc;
         if ((rc = launch_extprod_ntt(ctx, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count, ctx->stream))) return rc;
+    } else if (ctx->backend == RTFHE_BACKEND_FFT_SPLIT_EXACT) {
+        if ((rc = xfft_prepare(ctx))) return rc;
+        if ((rc = launch_extprod_xfft(ctx, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count, ctx->stream))) return rc;
     } else {
         ExtProdArgs a{ctx->d_tw, ctx->d_bk, (const int32_t*)ctx->d_b, (const uint32_t*)ctx->d_a, (uint32_t*)ctx->d_c, (int32_t)count};
         rc = ctx->logn == 10 ? launch_extprod_t<10>(ctx, a, ctx->stream) : launch_extprod_t<11>(ctx, a, ctx->stream);

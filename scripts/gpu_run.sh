@@ -3,12 +3,13 @@
 #   usage (through gpurun):  bash scripts/gpu_run.sh <tag> <step> [<step> ...]      outputs under gpurun_out/<tag>/
 # steps:
 #   tests            the GPU suite (pytest -m gpu, one process)
+#   testfile:<file>  one file of it
 #   smoke            __graft_entry__.smoke()
 #   bench            python bench.py (default flags: headline + cpu baseline + secondary)
 #   bench20          python bench.py --steps 20 --warmup 5 (the driver's flags)
 #   config3[:D]      bench.py --workload config3 on one GPU (RCCL harness); with D: --workload config3-c-abi over D entries naming GPU 0 (C-ABI sharding)
 #   ntt              bench.py --backend ntt-exact
-#   sweep[:N[:backend]]   scripts/sweep.py over the usual batch sizes (N = 1024 default, 2048; backend fft|ntt)
+#   sweep[:N[:backend]]   scripts/sweep.py over the usual batch sizes (N = 1024 default, 2048; backend fft|ntt|xfft)
 #   circuit          scripts/bench_circuit.py (the adder netlists)
 #   profile          rocprofv3 kernel trace + PMC passes of the headline (scripts/profile_gpu.sh r05)
 #   profile2048      counters of the N = 2048 kernel (scripts/profile_n2048.sh eo)
@@ -31,6 +32,7 @@ run() { local name=$1; shift; echo "== $name: $*"; "$@"; local rc=$?; echo "== $
 for step in "$@"; do
   IFS=: read -r kind a1 a2 a3 a4 a5 <<< "$step"
   case $kind in
+    testfile) run "tests $a1" bash -c "timeout -k 10 900 python -m pytest tests/$a1 -m gpu -x -q > $O/pytest_$a1.log 2>&1; rc=\$?; tail -15 $O/pytest_$a1.log; exit \$rc" ;;
     tests)   run tests bash -c "timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=\$?; tail -3 $O/pytest_gpu.log; exit \$rc" ;;
     smoke)   run smoke bash -c "timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; rc=\$?; tail -2 $O/smoke.log; exit \$rc" ;;
     bench)   run bench bash -c "timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; rc=\$?; cut -c1-400 $O/bench.json; exit \$rc" ;;
@@ -39,7 +41,7 @@ for step in "$@"; do
                run "config3 c-abi x$a1" bash -c "timeout -k 10 300 python bench.py --workload config3-c-abi --devices $devs --steps 3 --warmup 1 > $O/bench_config3_c_abi_$a1.json 2> $O/bench_config3_c_abi.err; rc=\$?; cut -c1-400 $O/bench_config3_c_abi_$a1.json; exit \$rc"
              else run config3 bash -c "timeout -k 10 300 python bench.py --workload config3 --steps 3 --warmup 1 > $O/bench_config3_1gpu.json 2> $O/bench_config3.err; rc=\$?; cut -c1-300 $O/bench_config3_1gpu.json; exit \$rc"; fi ;;
     ntt)     run ntt bash -c "timeout -k 10 300 python bench.py --backend ntt-exact --no-cpu-baseline > $O/bench_ntt_exact.json 2> $O/bench_ntt.err; rc=\$?; cut -c1-300 $O/bench_ntt_exact.json; exit \$rc" ;;
-    sweep)   n=${a1:-1024}; be=${a2:-fft}; sizes=1,256,512,768,1024,1280,1536,2048,4096,8192; [ $n = 2048 ] && sizes=1,256,512,768,1024,2048; [ $be = ntt ] && sizes=1,512,1024
+    sweep)   n=${a1:-1024}; be=${a2:-fft}; sizes=1,256,512,768,1024,1280,1536,2048,4096,8192; [ $n = 2048 ] && sizes=1,256,512,768,1024,2048; [ $be = ntt ] && sizes=1,512,1024; [ $be = xfft ] && sizes=1,256,512,768,1024,2048,4096
              run sweep env RTFHE_N=$n RTFHE_BACKEND=$be RTFHE_SKIP_STAGES=1 bash -c "timeout -k 10 300 python scripts/sweep.py $sizes > $O/sweep_N${n}_$be.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/sweep_N${n}_$be.log; exit \$rc" ;;
     circuit) run circuit bash -c "timeout -k 10 300 python scripts/bench_circuit.py > $O/bench_circuit.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/bench_circuit.log | tail -12; exit \$rc" ;;
     profile) run profile bash -c "bash scripts/profile_gpu.sh r05 > $O/profile.log 2>&1; rc=\$?; tail -3 $O/profile.log; cp -r gpurun_out/profiles_r05 $O/ 2>/dev/null; exit \$rc" ;;

@@ -14,6 +14,8 @@ eng = R.Engine(P, 0)
 eng.load_bk_torus(bk); eng.load_ksk(ksk)
 if os.environ.get('RTFHE_BACKEND') == 'ntt':
     eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+if os.environ.get('RTFHE_BACKEND') == 'xfft':
+    eng.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
 G = max(counts)
 rng = np.random.default_rng(0)
 b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
