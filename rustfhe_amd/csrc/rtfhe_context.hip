@@ -201,7 +201,8 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
         rc = fail(ctx, RTFHE_ERR_HIP, "hipEventCreate failed");
     if (rc) { g_last_error = ctx->err; rtfhe_ctx_destroy(ctx); return rc; }
 #ifdef RTFHE_WG_STAMPS
-    if (hipMalloc((void**)&ctx->d_dbg, 128 * 8) == hipSuccess) (void)hipMemset(ctx->d_dbg, 0, 128 * 8);
+    // 128 words of phase sums of workgroup 0 + 4 words per workgroup (first 1024): loop start, loop end (s_memtime), hardware id
+    if (hipMalloc((void**)&ctx->d_dbg, (128 + 4096) * 8) == hipSuccess) (void)hipMemset(ctx->d_dbg, 0, (128 + 4096) * 8);
 #endif
     *out = ctx;
     return 0;
@@ -261,6 +262,10 @@ void rtfhe_host_free(void* p) { if (p) (void)hipHostFree(p); }
 extern "C" int rtfhe_debug_read_stamps(rtfhe_ctx* ctx, unsigned long long* out128) {
     if (!ctx || !ctx->d_dbg) return RTFHE_ERR_STATE;
     return hipMemcpy(out128, ctx->d_dbg, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : RTFHE_ERR_HIP;
+}
+extern "C" int rtfhe_debug_read_wg_times(rtfhe_ctx* ctx, unsigned long long* out4096) {
+    if (!ctx || !ctx->d_dbg) return RTFHE_ERR_STATE;
+    return hipMemcpy(out4096, ctx->d_dbg + 128, 4096 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : RTFHE_ERR_HIP;
 }
 #endif
 

@@ -56,8 +56,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = wave % GATES;
     const int side = wave / GATES;
+#ifdef XF_REMAP
+    const int slot = (wave + side) % GATES;
+#else
+    const int slot = wave % GATES;
+#endif
     cplx* tw = reinterpret_cast<cplx*>(smem);
     for (int idx = tid; idx < xfft::XTw::TOTAL; idx += NT) tw[idx] = args.xtw[idx];
     cplx w1[7];       // forward pass 1: wave-uniform twiddles (scalar loads)
@@ -102,35 +106,61 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
         }
     }
     wave_lds_sync();
-    uint32_t own[2 * R];
-#pragma unroll
-    for (int mm = 0; mm < 2 * R; mm++) own[mm] = poly[lane + 64 * mm];
 
-    // key rows in consumption order rc = 0..11 of this side; a ring of two 8-point buffers across steps (even rc -> bA, odd -> bB), each refilled
-    // right after its multiply-accumulate retires
-    cplx bA[R], bB[R];
+    // key rows in consumption order rc = 0..11 of this side, as HALF rows hr = 2 rc + h (h: points 0..3 / 4..7 of the lane): a ring of THREE 4-point
+    // buffers across steps (half row hr lives in buffer hr % 3; 24 half rows per step, so the assignment is the same in every step), each refilled
+    // right after its multiply-accumulate retires.  Two whole-row buffers (64 registers) made the allocator spill at the peak of the step (three
+    // spectra + two accumulators + the ring), and scratch traffic shares the vector-memory path the key rows are bound by.
+    cplx kb[3][R / 2];
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t bk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(args.xbk), 0, 0x7fffffff, 0x00020000);
     const int lane16 = lane * 16;
-    constexpr int ROW_BYTES = R * 64 * (int)sizeof(cplx);
-    auto fetch = [&](cplx (&dst)[R], int step, int rc) {
-        const int s_lo = __builtin_amdgcn_readfirstlane(((step * 2 + side) * 12 + rc) * ROW_BYTES);
-        const int s_hi = s_lo + ROW_BYTES / 2;
+    constexpr int ROW_BYTES = R * 64 * (int)sizeof(cplx), HALF_ROWS = 24;
+    auto fetch = [&](cplx (&dst)[R / 2], int step, int hr) {
+#ifdef XF_HALF_KEYS      // timing only
+        if (hr >= 12) return;
+#endif
+        const int s_off = __builtin_amdgcn_readfirstlane(((step * 2 + side) * 12) * ROW_BYTES + hr * (ROW_BYTES / 2));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < R / 2; m++) {
-            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_lo, 0);
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_off, 0);
             dst[m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
-        }
-#pragma unroll
-        for (int m = 0; m < R / 2; m++) {
-            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + m * 1024, s_hi, 0);
-            dst[R / 2 + m] = make_double2(__longlong_as_double(((unsigned long long)v.y << 32) | v.x), __longlong_as_double(((unsigned long long)v.w << 32) | v.z));
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (a.steps > 0) { fetch(bA, 0, 0); fetch(bB, 0, 1); }
+    if (a.steps > 0) { fetch(kb[0], 0, 0); fetch(kb[1], 0, 1); fetch(kb[2], 0, 2); }
+#ifdef XF_STAGGER
+    if (slot & 1) { for (int k = 0; k < XF_STAGGER; k++) __builtin_amdgcn_s_sleep(100); }
+#endif
 
+    // Priority schedule.  Of two busy waves a SIMD runs one at nearly full speed (the older one unless s_setprio says otherwise) and the other on
+    // the leftovers: with equal priorities side 0 reached every hand-off ~8 k cycles early and the SIMD then ran a single wave
+    // (profiles/r06/xfft_phase_stamps.log).  Side 1 stays at priority 1; side 0 alternates between 2 and 0 from one point to the next, so the two
+    // sides trade the lead every segment and arrive together.
+    auto prio = [&](int k) {
+#ifndef XF_NO_PRIO
+        if (k & 1) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
+        else asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
+#endif
+    };
+#ifndef XF_NO_PRIO
+    if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#endif
+#ifdef RTFHE_WG_STAMPS
+    unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_loop0 = tprev, rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifndef XF_P0
+#define XF_P0 0
+#endif
+#ifdef XF_NO_BARRIER     // timing only
+#define XF_SYNC(k) do { } while (0)
+#elif defined(XF_FLAGS)
+#define XF_SYNC(k) do { pair_arrive(my_flag, 2u * (unsigned)i + (k)); xfft::pair_wait_sleepy(partner_flag, 2u * (unsigned)i + (k)); } while (0)
+#else
+#define XF_SYNC(k) do { if constexpr (FLAG_SYNC) { pair_arrive(my_flag, 2u * (unsigned)i + (k)); xfft::pair_wait_sleepy(partner_flag, 2u * (unsigned)i + (k)); } else lds_barrier(); } while (0)
+#endif
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
 #pragma unroll
         for (int mm = 0; mm < 2 * R; mm++) {
             const int c = ln + 64 * mm;
-            u[mm] = ((rotated_coef<LOGN>(poly, c, r) - own[mm]) + M) ^ M;
+            u[mm] = ((rotated_coef<LOGN>(poly, c, r) - poly[c]) + M) ^ M;
         }
         double xr[L][R], xi[L][R];
 #pragma unroll
@@ -152,7 +182,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
                 xi[jj][m] = (double)decomp_digit(u[R + m], BGBIT, jj);
             }
         }
-        xfft::forward_multi<L>(xr, xi, tw, w1, myx, myx + G::XSLOTS, ln);
+        PAIR_STAMP(0);
+        prio(XF_P0 + 1);
+        xfft::forward_multi<L>(xr, xi, tw, w1, myx, myx + G::XSLOTS, ln, [&](int k) { prio(XF_P0 + 1 + k); });
+        PAIR_STAMP(1);
+        prio(XF_P0 + 4);
 
         double sre[2][R], sim[2][R];       // [0]: hi half, [1]: lo half of the own output polynomial; the partner's partials pass through [1]
         auto put = [&](cplx* h, const double (&pr)[R], const double (&pi)[R]) {
@@ -163,40 +197,64 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
 #pragma unroll
             for (int m = 0; m < R; m++) { const cplx v = h[m * 64]; pr[m] = v.x; pi[m] = v.y; }
         };
-        // M1: hi half of the partner's polynomial over the own rows -> own buffer
-        xfft::mac<true>(sre[1], sim[1], bA, xr[0], xi[0]); fetch(bA, i, 2);
-        xfft::mac<false>(sre[1], sim[1], bB, xr[1], xi[1]); fetch(bB, i, 3);
-        xfft::mac<false>(sre[1], sim[1], bA, xr[2], xi[2]); fetch(bA, i, 4);
-        put(hand_mine, sre[1], sim[1]);
-        if constexpr (FLAG_SYNC) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u); else lds_barrier();
-        // M2: hi half of the own polynomial on top of the partner's partial
-        get(hand_peer, sre[0], sim[0]);
-        xfft::mac<false>(sre[0], sim[0], bB, xr[0], xi[0]); fetch(bB, i, 5);
-        xfft::mac<false>(sre[0], sim[0], bA, xr[1], xi[1]); fetch(bA, i, 6);
-        xfft::mac<false>(sre[0], sim[0], bB, xr[2], xi[2]); fetch(bB, i, 7);
-        // M3: lo half of the partner's polynomial -> the partner's buffer (read above: free)
-        xfft::mac<true>(sre[1], sim[1], bA, xr[0], xi[0]); fetch(bA, i, 8);
-        xfft::mac<false>(sre[1], sim[1], bB, xr[1], xi[1]); fetch(bB, i, 9);
-        xfft::mac<false>(sre[1], sim[1], bA, xr[2], xi[2]); fetch(bA, i, 10);
-        put(hand_peer, sre[1], sim[1]);
-        if constexpr (FLAG_SYNC) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();
-        // M4: lo half of the own polynomial on top of the partner's partial
-        get(hand_mine, sre[1], sim[1]);
-        xfft::mac<false>(sre[1], sim[1], bB, xr[0], xi[0]); fetch(bB, i, 11);
-        xfft::mac<false>(sre[1], sim[1], bA, xr[1], xi[1]); fetch(bA, nxt, 0);
-        xfft::mac<false>(sre[1], sim[1], bB, xr[2], xi[2]); fetch(bB, nxt, 1);
+        // the four multiply-accumulate phases over the 24 half rows of this side (phase = hr / 6, row = hr % 6 / 2, half = hr % 2)
+        //   phase 0 (M1): hi half of the PARTNER's polynomial over the own rows -> own buffer, then the first hand-off
+        //   phase 1 (M2): hi half of the OWN polynomial on top of the partner's partial
+        //   phase 2 (M3): lo half of the partner's polynomial -> the PARTNER's buffer (read in phase 1: free), then the second hand-off
+        //   phase 3 (M4): lo half of the own polynomial on top of the partner's partial
+#pragma unroll
+        for (int hr = 0; hr < HALF_ROWS; hr++) {
+            const int phase = hr / 6, row = (hr % 6) / 2, h = hr & 1;
+            if (hr == 6) {
+                put(hand_mine, sre[1], sim[1]);
+                PAIR_STAMP(2);
+                XF_SYNC(1u);
+                PAIR_STAMP(3);
+                prio(XF_P0 + 5);
+                get(hand_peer, sre[0], sim[0]);
+            }
+            if (hr == 12) prio(XF_P0 + 6);
+            if (hr == 18) {
+                put(hand_peer, sre[1], sim[1]);
+                PAIR_STAMP(4);
+                XF_SYNC(2u);
+                PAIR_STAMP(5);
+                prio(XF_P0 + 7);
+                get(hand_mine, sre[1], sim[1]);
+            }
+            const bool first = (phase == 0 || phase == 2) && row == 0;
+            if (phase == 1) xfft::mac_half(sre[0], sim[0], kb[hr % 3], xr[row], xi[row], h, first);
+            else xfft::mac_half(sre[1], sim[1], kb[hr % 3], xr[row], xi[row], h, first);
+            fetch(kb[hr % 3], hr + 3 < HALF_ROWS ? i : nxt, (hr + 3) % HALF_ROWS);
+        }
 
-        xfft::inverse_multi<2>(sre, sim, tw, myx, myx + G::XSLOTS, lane);
+        PAIR_STAMP(6);
+        prio(XF_P0 + 8);
+        xfft::inverse_multi<2>(sre, sim, tw, myx, myx + G::XSLOTS, lane, [&](int k) { prio(XF_P0 + 8 + k); });
+        PAIR_STAMP(7);
+        prio(XF_P0 + 11);
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
-            own[m] += xfft::rounded_hi16(sre[0][m]) + xfft::rounded_u32(sre[1][m]);
-            own[R + m] += xfft::rounded_hi16(sim[0][m]) + xfft::rounded_u32(sim[1][m]);
-            poly[c] = own[m];
-            poly[c + P] = own[R + m];
+            // ds_add_u32: no read-back, and no 16 registers of own coefficients live across the step (they spilled)
+            __hip_atomic_fetch_add(&poly[c], xfft::rounded_hi16(sre[0][m]) + xfft::rounded_u32(sre[1][m]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&poly[c + P], xfft::rounded_hi16(sim[0][m]) + xfft::rounded_u32(sim[1][m]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         wave_lds_sync();
+        PAIR_STAMP(8);
+        prio(XF_P0 + 12);
     }
+    __builtin_amdgcn_s_setprio(0);
+#ifdef RTFHE_WG_STAMPS
+    if (a.dbg && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; k++) a.dbg[wave * 16 + k] = tsum[k];
+    if (a.dbg && blockIdx.x < 1024 && tid == 0) {
+        a.dbg[128 + 4 * blockIdx.x] = t_loop0;
+        a.dbg[128 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        a.dbg[128 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime() - rt_loop0;      // 100 MHz
+        a.dbg[128 + 4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    }
+#endif
 
     if (a.mode == MODE_BLIND_ROTATE) {
         if (live) {

@@ -133,6 +133,25 @@ __device__ __forceinline__ uint32_t rounded_hi16(double v) {
     return (uint32_t)__double_as_longlong(v) & 0xFFFF0000u;
 }
 
+// waits until the partner's arrival counter (LDS) has reached k; sleeps between polls so that the poll costs the SIMD's other wave next to nothing
+__device__ __forceinline__ void pair_wait_sleepy(unsigned partner_flag_addr, unsigned k) {
+    unsigned v, t;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %1, %0\n\t"
+        "s_sub_i32 %1, %1, %3\n\t"
+        "s_cmp_lt_i32 %1, 0\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n"
+        "2:"
+        : "=&v"(v), "=&s"(t)
+        : "v"(partner_flag_addr), "s"(k)
+        : "memory", "scc");
+}
+
 // s (+)= b * x, 4 FMA per point; FIRST: s = b * x
 template <bool FIRST>
 __device__ __forceinline__ void mac(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&xr)[R], const double (&xi)[R]) {
@@ -145,13 +164,26 @@ __device__ __forceinline__ void mac(double (&sre)[R], double (&sim)[R], const cp
     }
 }
 
+// the same over one half of a lane's points (h = 0: points 0..3, 1: points 4..7): the key arrives in half rows (rtfhe_kernels_xfft.hpp)
+__device__ __forceinline__ void mac_half(double (&sre)[R], double (&sim)[R], const cplx (&b)[R / 2], const double (&xr)[R], const double (&xi)[R], int h, bool first) {
+#pragma unroll
+    for (int k = 0; k < R / 2; k++) {
+        const int m = h * (R / 2) + k;
+        const double r0 = first ? b[k].x * xr[m] : __builtin_fma(b[k].x, xr[m], sre[m]);
+        const double i0 = first ? b[k].x * xi[m] : __builtin_fma(b[k].x, xi[m], sim[m]);
+        sre[m] = __builtin_fma(-b[k].y, xi[m], r0);
+        sim[m] = __builtin_fma(b[k].y, xr[m], i0);
+    }
+}
+
 // NR forward transforms side by side in one wave.  in: layout L1 (re[j][m], im[j][m] = folded point lane + 64 m of row j); out: layout L3
 // (position (lane << 3) | m, bit-reversed frequency order -- the order the key is stored in).  tw: LDS table (XTw); the seven pass-1 twiddles
 // come as w1 (registers / scalars of the caller).  A row's exchange reads are issued between the stages of the NEXT row's pass (as
 // fft_forward_multi_a's interleaved form, rtfhe_device.hpp).
-template <int NR, typename HOOK = NoHook>
+struct NoPoint { __device__ __forceinline__ void operator()(int) const {} };
+template <int NR, typename HOOK = NoPoint>
 __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ tw, const cplx (&w1)[7],
-                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK after_pass1 = HOOK()) {
+                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
     typedef XAffine<10, 1, 2> X1;
     typedef XAffine<10, 2, 3> X2;
     auto pass = [&](int j, const cplx* w, auto&& between0, auto&& between1) {
@@ -182,7 +214,7 @@ __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[
         X1::write(re[j], im[j], xbuf, xim, lane);
         wave_lds_sync();
     }
-    after_pass1();
+    point(1);
     Tw<7> w2;
     w2.load(tw + XTw::F2 + (lane >> 3), 8);
 #pragma unroll
@@ -192,6 +224,7 @@ __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[
         X2::write(re[j], im[j], xbuf, xim, lane);
         wave_lds_sync();
     }
+    point(2);
     Tw<7> w3;
     w3.load(tw + XTw::F3 + lane, 64);
 #pragma unroll
@@ -203,9 +236,9 @@ __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[
 
 // NR inverse transforms side by side.  in: layout L3 (the multiply-accumulate's sums); out: layout L1, untwisted, scaled and carrying MAGIC
 // (re[j][m] <-> coefficient lane + 64 m, im[j][m] <-> coefficient lane + 64 m + N/2; read with rounded_u32 / rounded_hi16).
-template <int NR>
+template <int NR, typename HOOK = NoPoint>
 __device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ tw,
-                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane) {
+                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
     typedef XAffine<10, 3, 2> X1;
     typedef XAffine<10, 2, 1> X2;
 #pragma unroll
@@ -215,6 +248,7 @@ __device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[
         X1::write(re[j], im[j], xbuf, xim, lane);
         wave_lds_sync();
     }
+    point(1);
     Tw<7> w2;
     w2.load(tw + XTw::I2 + (lane & 7), 8);
 #pragma unroll
@@ -225,6 +259,7 @@ __device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[
         X2::write(re[j], im[j], xbuf, xim, lane);
         wave_lds_sync();
     }
+    point(2);
     Tw<7> w3;
     w3.load(tw + XTw::I3 + lane, 64);
 #pragma unroll

@@ -35,6 +35,8 @@ for spec in libs:
     e.load_bk_torus(bk); e.load_ksk(ksk)
     if os.environ.get("RTFHE_BACKEND") == "ntt":
         e.set_backend(1)
+    if os.environ.get("RTFHE_BACKEND") == "xfft":
+        e.set_backend(2)
     engines.append(e); outs.append(torch.empty_like(d0))
     for kv in envs:
         del os.environ[kv.split("=")[0]]
