@@ -399,6 +399,19 @@ def supervise(child_cmd, env=None):
     return 0
 
 
+def xfft_dp_wave_instr_per_cmux(N=1024, l=3):
+    """FP64-rate VALU wave-instructions of one CMUX step on the split-FFT exact backend (rustfhe_amd/csrc/rtfhe_xfft.hpp,
+    rtfhe_kernels_xfft.hpp; the same count as scripts/xfft/model.py, checked against the built kernel's ISA by tests/test_bench_launcher.py).
+    Every one of them but the conversions is a v_fma_f64 / v_fmac_f64 (or an addition of the first inverse pass): two flops each against the
+    78.6 TFLOP/s FMA peak is the same fraction as one instruction each against the 39.3 T lane-instructions/s issue ceiling."""
+    assert N == 1024 and l == 3
+    R = 8
+    fwd = 3 * 12 * 6                                               # three passes of 12 radix-2 butterflies, 6 FMAs each; the twist is in the twiddles
+    inv = (4 * 4 + 4 * 4 + 2 * 4 + 2 * 6) + 2 * 12 * 6             # first pass on twiddles 1, -i, (+-1 - i)/sqrt 2; two full passes
+    per_wave = {"cvt": l * 2 * R, "forward": l * fwd, "mac": 4 * l * R * 4, "inverse": 2 * inv, "untwist_round": 2 * 2 * R * 2}
+    return {**per_wave, "per_wave": sum(per_wave.values()), "total": 2 * sum(per_wave.values())}
+
+
 def fp64_frac(dp_per_cmux, n, gates, seconds):
     """fraction of the FP64 vector-issue ceiling a launch of `gates` gates taking `seconds` reaches"""
     return round(dp_per_cmux * n * 64 * gates / seconds / FP64_VALU_PEAK, 4)
@@ -549,6 +562,26 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
         sec["ntt_exact_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_ntt_pair",
                                        "roofline_frac_fp64": fp64_frac(nops, params.n, G, ms * 1e-3), "ok": okn}
     guard("ntt_exact_1024_gates", _ntt_exact_1024_gates)
+    # -- the same exact products through the split FFT (RTFHE_BACKEND_FFT_SPLIT_EXACT): 1024 gates, every output word equal to the NTT backend's
+    def _xfft_exact_1024_gates():
+        G = 1024
+        bb = rng.integers(0, 2, (2, G)).astype(np.uint8)
+        d0 = torch.from_numpy(R.encrypt_bits(params, key0, bb[0], 41).view(np.int32)).to(gpu)
+        d1 = torch.from_numpy(R.encrypt_bits(params, key0, bb[1], 42).view(np.int32)).to(gpu)
+        do, dn = torch.empty_like(d0), torch.empty_like(d0)
+        eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        eng.gate_batch_dev(R.NAND, d0, d1, dn, G, stream); eng.sync(stream)
+        eng.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        ms, _ = timed(eng, lambda: eng.gate_batch_dev(R.NAND, d0, d1, do, G, stream), 5)
+        okx = bool(np.array_equal(R.decrypt_bits(params, key0, do.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+        same = bool(torch.equal(do, dn))
+        eng.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+        xops = xfft_dp_wave_instr_per_cmux(params.N, params.l)["total"]
+        sec["xfft_exact_1024_gates"] = {"gates_per_s": round(G / ms * 1e3, 1), "ms_per_launch": round(ms, 3), "kernel": "k_bootstrap_xpair",
+                                        "dp_wave_instr_per_cmux": xops, "roofline_frac_fp64_fma": fp64_frac(xops, params.n, G, ms * 1e-3),
+                                        "frac_is": "v_fma_f64 issue: 2 flops each against 78.6 TFLOP/s = 1 instruction each against 39.3 T lane-instructions/s",
+                                        "equals_ntt_exact_bit_for_bit": same, "ok": okx}
+    guard("xfft_exact_1024_gates", _xfft_exact_1024_gates)
     # -- tail behaviour on the driver's clock: batches that do not fill whole rounds of 4 gates per CU (default dispatch: a remainder of
     #    <= 1 gate per CU on the latency shape, <= 2 / <= 3 per CU on 2 / 3 gates per workgroup); two untimed launches, then three timed
     def _batch_sweep():
@@ -729,6 +762,8 @@ def run_rank(args):
     key_s = time.perf_counter() - t_key
     if args.backend == "ntt-exact":
         eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+    if args.backend == "split-fft-exact":
+        eng.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
 
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -814,7 +849,7 @@ def run_rank(args):
         ks_s = ks_ms * 1e-3 / args.steps                # of it: the batch key switch of the split path (its own launch; 0 when fused)
         launch_s = step_s - ks_s                        # the dominant kernel: blind rotation (+ fused key switch when not split)
         mirror = args.backend == "fft64-mirror"
-        kernel = "k_bootstrap_pair" if mirror else "k_bootstrap_ntt_pair"
+        kernel = "k_bootstrap_pair" if mirror else ("k_bootstrap_xpair" if args.backend == "split-fft-exact" else "k_bootstrap_ntt_pair")
         ops = dp_wave_instr_per_cmux(params.N, params.l)
         line = {
             "metric": "HomNAND gates/sec (whole node), N=1024", "value": round(value, 1), "unit": "gates/s",
@@ -863,7 +898,7 @@ def run_rank(args):
                     "note": "includes the memset of the output; 25 % of the contraction's K are the zero rows of digit 0"}
         else:
             # same ceiling (FP64-rate vector issue; the NTT's v_fma_f64 count as one instruction each)
-            nops = ntt_dp_wave_instr_per_cmux(params.N, params.l)
+            nops = xfft_dp_wave_instr_per_cmux(params.N, params.l) if args.backend == "split-fft-exact" else ntt_dp_wave_instr_per_cmux(params.N, params.l)
             dp_gate = nops["total"] * params.n
             achieved = dp_gate * 64 * G / launch_s
             line["roofline"] = {
@@ -980,8 +1015,9 @@ def main():
                          "inside the library by a multi-device context over --devices, one process")
     ap.add_argument("--devices", default="0", help="config3-c-abi: comma-separated device ids of the multi-device context (an id may repeat)")
     ap.add_argument("--gates", type=int, default=0, help="gates per GPU per step (default 1024, config3: 8192)")
-    ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact"], default="fft64-mirror",
-                    help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT")
+    ap.add_argument("--backend", choices=["fft64-mirror", "ntt-exact", "split-fft-exact"], default="fft64-mirror",
+                    help="fft64-mirror (default): bit-identical to the reference CPU path; ntt-exact: exact-integer NTT; split-fft-exact: the same "
+                         "exact products through an FMA FP64 FFT with the key in 16-bit halves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs / NTT backend measured after the headline")
     ap.add_argument("--cpu-gates-per-thread", type=int, default=24, help="least number of gates every thread of the all-core CPU baseline runs")

@@ -2,23 +2,24 @@
 // the key transform and the stage-level external product.
 //
 // k_bootstrap_xpair keeps k_bootstrap_pair's skeleton (rtfhe_kernels_pair.hpp: side 0 owns the b-polynomial, side 1 the a-polynomial; gather and
-// decomposition from the own polynomial only; accumulator in LDS, own coefficients handed from step to step in registers; key rows through a
-// buffer resource into a two-buffer register ring; the same prologue and epilogue) and replaces the CMUX step's arithmetic:
+// decomposition from the own polynomial only; accumulator in LDS; key rows through a buffer resource into a register ring; the same prologue and
+// epilogue) and replaces the CMUX step's arithmetic:
 //
 //   both sides, the same code (exact sums have no order, so the split is symmetric):
 //   gather / decompose the own polynomial, three forward transforms side by side                                  (spectra in VGPRs)
 //   M1: hi-half partial of the PARTNER's output polynomial over the own three rows            -> own exchange buffer
-//   ------------------------------------------------------ barrier 1 ----------------------------------------------
+//   ---------------------------------------------- hand-off 1 (the pair's arrival flags) ---------------------------
 //   M2: S_hi = the partner's partial (read from ITS exchange buffer) + own three rows of the OWN output polynomial, hi half
 //   M3: lo-half partial of the partner's polynomial                                           -> the PARTNER's exchange buffer (just read: free)
-//   ------------------------------------------------------ barrier 2 ----------------------------------------------
+//   ---------------------------------------------- hand-off 2 ------------------------------------------------------
 //   M4: S_lo = the partner's partial (read from the OWN exchange buffer) + own three rows, lo half
 //   two inverse transforms side by side (hi, lo), untwist fused with the rounding; own polynomial += (hi << 16) + lo  (mod 2^32)
 //
 // Why the hand-off takes two phases: a side owes its partner two spectra (16 KiB); the idle exchange buffers hold one each (4 gates per CU
 // leave no more LDS).  Every buffer has one writer and one reader per phase and DS instructions of a wave execute in order:
-//   own buffer    : written by me (forward exchanges, M1) before barrier 1; read by the partner (M2) and then written by the partner (M3)
-//                   between the barriers; read by me (M4) and reused by my inverse transforms after barrier 2.
+//   own buffer    : written by me (forward exchanges, M1) before hand-off 1; read by the partner (M2) and then written by the partner (M3)
+//                   between the hand-offs; read by me (M4) and reused by my inverse transforms after hand-off 2.
+// A hand-off is the two waves of ONE gate meeting through flags in LDS; nothing in the step loop ever waits for another gate (see XF_SYNC).
 #pragma once
 
 #include "rtfhe_kernels.hpp"
@@ -51,17 +52,12 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
     constexpr int N = G::N, P = G::P, R = G::R, NT = 128 * GATES;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3 && R == xfft::R, "three rows per side are held in registers");
-    constexpr bool FLAG_SYNC = GATES < 4;      // as k_bootstrap_pair: the workgroup barrier when the workgroup is full, pair flags when it is not
     const BootstrapArgs& a = args.b;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int side = wave / GATES;
-#ifdef XF_REMAP
-    const int slot = (wave + side) % GATES;
-#else
     const int slot = wave % GATES;
-#endif
     cplx* tw = reinterpret_cast<cplx*>(smem);
     for (int idx = tid; idx < xfft::XTw::TOTAL; idx += NT) tw[idx] = args.xtw[idx];
     cplx w1[7];       // forward pass 1: wave-uniform twiddles (scalar loads)
@@ -71,7 +67,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
     const int g_raw = blockIdx.x * GATES + slot;
     const int g = g_raw < a.count ? g_raw : a.count - 1;
     const GateIo io = gate_io(a, g);
-    const bool live = g_raw < a.count && io.ok;      // idle / skipped pairs still take part in every barrier
+    const bool live = g_raw < a.count && io.ok;      // idle / skipped pairs still run every step and take part in the barriers of the prologue and epilogue
 
     unsigned char* gbase = smem + XPairLds::TW + (size_t)slot * XPairLds::gate_bytes(a.npad);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);
@@ -81,8 +77,9 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
     double* myx = side ? xb1 : xb0;
     uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + XPairLds::gate_bytes(a.npad) - XPairLds::FLAGS);
     if (lane == 0) flags[side] = 0u;
-    [[maybe_unused]] const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side);
-    [[maybe_unused]] const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side));
+    // LDS addresses of the flags as scalars (rtfhe_xfft.hpp: flag_arrive)
+    const unsigned my_flag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side));
+    const unsigned partner_flag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side)));
     cplx* hand_mine = reinterpret_cast<cplx*>(myx) + lane;                       // [R][64] cplx
     cplx* hand_peer = reinterpret_cast<cplx*>(side ? xb0 : xb1) + lane;
     uint32_t* poly = accbuf + side * N;
@@ -117,9 +114,6 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
     const int lane16 = lane * 16;
     constexpr int ROW_BYTES = R * 64 * (int)sizeof(cplx), HALF_ROWS = 24;
     auto fetch = [&](cplx (&dst)[R / 2], int step, int hr) {
-#ifdef XF_HALF_KEYS      // timing only
-        if (hr >= 12) return;
-#endif
         const int s_off = __builtin_amdgcn_readfirstlane(((step * 2 + side) * 12) * ROW_BYTES + hr * (ROW_BYTES / 2));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -130,37 +124,28 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
         __builtin_amdgcn_sched_barrier(0);
     };
     if (a.steps > 0) { fetch(kb[0], 0, 0); fetch(kb[1], 0, 1); fetch(kb[2], 0, 2); }
-#ifdef XF_STAGGER
-    if (slot & 1) { for (int k = 0; k < XF_STAGGER; k++) __builtin_amdgcn_s_sleep(100); }
-#endif
 
     // Priority schedule.  Of two busy waves a SIMD runs one at nearly full speed (the older one unless s_setprio says otherwise) and the other on
-    // the leftovers: with equal priorities side 0 reached every hand-off ~8 k cycles early and the SIMD then ran a single wave
-    // (profiles/r06/xfft_phase_stamps.log).  Side 1 stays at priority 1; side 0 alternates between 2 and 0 from one point to the next, so the two
-    // sides trade the lead every segment and arrive together.
+    // the leftovers: with equal priorities one side reaches every hand-off thousands of cycles early and the SIMD then runs a single wave.  Side 1
+    // stays at priority 1; side 0 alternates between 2 and 0 from one point to the next, so the two sides trade the lead every segment (without
+    // s_setprio: 7.55 against 7.20 ms per 1,024 gates; what is left is side 1 waiting ~5 k of the step's 24.8 k cycles at the hand-offs:
+    // profiles/r06/xfft_sync_forms.log, xfft_phase_stamps_flags_build.log).
     auto prio = [&](int k) {
-#ifndef XF_NO_PRIO
         if (k & 1) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
         else asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
-#endif
     };
-#ifndef XF_NO_PRIO
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
-#endif
 #ifdef RTFHE_WG_STAMPS
     unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long t_loop0 = tprev, rt_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifndef XF_P0
-#define XF_P0 0
-#endif
-#ifdef XF_NO_BARRIER     // timing only
-#define XF_SYNC(k) do { } while (0)
-#elif defined(XF_FLAGS)
-#define XF_SYNC(k) do { pair_arrive(my_flag, 2u * (unsigned)i + (k)); xfft::pair_wait_sleepy(partner_flag, 2u * (unsigned)i + (k)); } while (0)
-#else
-#define XF_SYNC(k) do { if constexpr (FLAG_SYNC) { pair_arrive(my_flag, 2u * (unsigned)i + (k)); xfft::pair_wait_sleepy(partner_flag, 2u * (unsigned)i + (k)); } else lds_barrier(); } while (0)
-#endif
+    // The two waves of a gate meet through their arrival flags (rtfhe_xfft.hpp: flag_arrive / flag_wait), never through the workgroup barrier, at
+    // every number of gates per workgroup.  Gates held in lock step collide phase by phase on what a CU shares (LDS, the vector-memory path);
+    // gates that drift apart spread that load.  Measured at 1,024 gates (profiles/r06/xfft_sync_forms.log): workgroup barrier 8.21-8.31 ms, pair
+    // flags 7.20-7.43 ms, no synchronisation at all (wrong results, timing only) 7.30 ms.  Lock step does buy L1 hits -- the four waves of one side
+    // read the same key rows: 254 M requests to L2 per launch under the barrier against 974 M with flags -- and loses all the same: flags plus a
+    // counter that keeps one side's four waves together 8.13-8.47 ms, pairs of gates kept together (527 M requests) 7.65-7.79 ms.
+#define XF_SYNC(k) do { xfft::flag_arrive(my_flag, 2u * (unsigned)i + (k)); xfft::flag_wait(partner_flag, 2u * (unsigned)i + (k)); } while (0)
 #pragma unroll 1
     for (int i = 0; i < a.steps; i++) {
         const int r = __builtin_amdgcn_readfirstlane((int)abar[i]);
@@ -183,10 +168,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
             }
         }
         PAIR_STAMP(0);
-        prio(XF_P0 + 1);
-        xfft::forward_multi<L>(xr, xi, tw, w1, myx, myx + G::XSLOTS, ln, [&](int k) { prio(XF_P0 + 1 + k); });
+        prio(1);
+        xfft::forward_multi<L>(xr, xi, tw, w1, myx, myx + G::XSLOTS, ln, [&](int k) { prio(1 + k); });
         PAIR_STAMP(1);
-        prio(XF_P0 + 4);
+        prio(4);
 
         double sre[2][R], sim[2][R];       // [0]: hi half, [1]: lo half of the own output polynomial; the partner's partials pass through [1]
         auto put = [&](cplx* h, const double (&pr)[R], const double (&pi)[R]) {
@@ -210,16 +195,16 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
                 PAIR_STAMP(2);
                 XF_SYNC(1u);
                 PAIR_STAMP(3);
-                prio(XF_P0 + 5);
+                prio(5);
                 get(hand_peer, sre[0], sim[0]);
             }
-            if (hr == 12) prio(XF_P0 + 6);
+            if (hr == 12) prio(6);
             if (hr == 18) {
                 put(hand_peer, sre[1], sim[1]);
                 PAIR_STAMP(4);
                 XF_SYNC(2u);
                 PAIR_STAMP(5);
-                prio(XF_P0 + 7);
+                prio(7);
                 get(hand_mine, sre[1], sim[1]);
             }
             const bool first = (phase == 0 || phase == 2) && row == 0;
@@ -229,10 +214,10 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
         }
 
         PAIR_STAMP(6);
-        prio(XF_P0 + 8);
-        xfft::inverse_multi<2>(sre, sim, tw, myx, myx + G::XSLOTS, lane, [&](int k) { prio(XF_P0 + 8 + k); });
+        prio(8);
+        xfft::inverse_multi<2>(sre, sim, tw, myx, myx + G::XSLOTS, lane, [&](int k) { prio(8 + k); });
         PAIR_STAMP(7);
-        prio(XF_P0 + 11);
+        prio(11);
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int c = lane + 64 * m;
@@ -242,7 +227,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_xpair(const XBoots
         }
         wave_lds_sync();
         PAIR_STAMP(8);
-        prio(XF_P0 + 12);
+        prio(12);
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef RTFHE_WG_STAMPS
