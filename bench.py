@@ -367,11 +367,17 @@ class CpuBaselineChild:
 # ------------------------------------------------------------------------------------------------------------------
 # supervisor (N = 1, plain `python bench.py`): the measuring process runs as a child; the headline survives its death
 # ------------------------------------------------------------------------------------------------------------------
+SIDE_LEG_CRASH_RC = 86
+
+
 def supervise(child_cmd, env=None):
     """Runs the measuring process as a child with RTFHE_BENCH_INNER=1 and prints exactly ONE JSON line: the LAST complete line the
     child produced.  The child prints its line as soon as the headline is complete (marked "provisional") and again after each side
     leg (CPU baseline, secondary measurements); if it then dies -- a native crash in a side kernel, an abort() in a library -- the
-    headline measured before is printed with the crash recorded in it, and the exit code is 0.  No line at all = the child's exit code."""
+    headline measured before is printed with the crash recorded in it: top-level "ok": false and "side_leg_crash" (a complete run carries
+    "ok": true).  The exit code then is SIDE_LEG_CRASH_RC (86) when RTFHE_BENCH_STRICT=1 is set -- scripts/gpu_run.sh sets it, so a GPU fault in
+    a side kernel fails the evidence run -- and 0 otherwise, so that a driver that gates on the exit code alone does not lose the headline it
+    came for (the line says what happened either way).  No line at all = the child's exit code."""
     e = dict(os.environ if env is None else env)
     e["RTFHE_BENCH_INNER"] = "1"
     proc = subprocess.Popen(list(child_cmd), stdout=subprocess.PIPE, text=True, env=e)
@@ -390,11 +396,17 @@ def supervise(child_cmd, env=None):
         return rc if rc > 0 else 1
     pending = last.pop("provisional", None)
     if rc != 0:
+        strict = os.environ.get("RTFHE_BENCH_STRICT") == "1"
         sys.stderr.write("bench.py: THE MEASURING PROCESS DIED (rc %s, %s) after the headline was complete; legs not completed: %s -- the line "
-                         "below carries side_leg_crash, the exit code stays 0 so that the headline is not lost\n" % (rc, _signal_name(rc), pending))
+                         "below carries \"ok\": false and side_leg_crash; exit code %d (RTFHE_BENCH_STRICT=1 makes it %d)\n"
+                         % (rc, _signal_name(rc), pending, SIDE_LEG_CRASH_RC if strict else 0, SIDE_LEG_CRASH_RC))
+        last["ok"] = False
         last["side_leg_crash"] = {"rc": rc, "signal": _signal_name(rc), "legs_not_completed": pending,
                                   "note": "the measuring process died AFTER the headline above was complete; the value, roofline and every leg "
                                           "present in this line were measured before that"}
+        print(json.dumps(last), flush=True)
+        return SIDE_LEG_CRASH_RC if strict else 0
+    last["ok"] = True
     print(json.dumps(last), flush=True)
     return 0
 
@@ -738,8 +750,17 @@ def run_rank(args):
         peers = [d for d in range(ndev) if d != dev and torch.cuda.can_device_access_peer(dev, d)]
         props = torch.cuda.get_device_properties(dev)
         ident = "%s/%s" % (getattr(props, "uuid", ""), getattr(props, "pci_bus_id", dev))
-        sys.stderr.write("bench.py rank %d/%d: device %d of %d (%s, %s), backend %s, communicator world size %d, P2P-reachable peers %s, "
-                         "HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (rank, world, dev, ndev, torch.cuda.get_device_name(dev), ident, backend, n_gpus, peers,
+        # ... and the link the runtime reports from this rank's card to every other card of the node (queries only)
+        links = {}
+        for d in range(ndev):
+            if d != dev:
+                try:
+                    lk = R.device_link(dev, d)
+                    links[d] = "%s/%d hop%s%s" % (lk["link"], lk["hops"], "" if lk["hops"] == 1 else "s", "" if lk["can_access"] else " (no peer access)")
+                except Exception as e:      # noqa: BLE001
+                    links[d] = "query failed: %s" % e
+        sys.stderr.write("bench.py rank %d/%d: device %d of %d (%s, %s), backend %s, communicator world size %d, P2P-reachable peers %s, links %s, "
+                         "HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (rank, world, dev, ndev, torch.cuda.get_device_name(dev), ident, backend, n_gpus, peers, links,
                                                               os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
         # a whole-node number is only a whole-node number if every rank drives a card of its own: under RCCL the ranks compare device
         # identities and the job refuses to print a line when two of them share one
@@ -786,6 +807,24 @@ def run_rank(args):
             in1 = R.encrypt_bits(params, key0, b1, 5001)
             full0 = torch.from_numpy(in0.view(np.int32)).to(comm)
             full1 = torch.from_numpy(in1.view(np.int32)).to(comm)
+        # self-check before anything is timed: the batch as scattered, bootstrapped on every rank and gathered must be, word
+        # for word, what rank 0's card computes alone on the first 2 x 8192 gates -- on distinct devices this is the first time the P2P
+        # sends / receives carry real data, and a job that fails here prints no line
+        check = sg.run(R.NAND, full0, full1, total)
+        if world > 1:
+            verdict = torch.zeros(1, dtype=torch.int32, device=comm)
+            if rank == 0:
+                Gc = min(total, 2 * 8192)
+                ref = torch.empty((Gc, params.n + 1), dtype=torch.int32, device=gpu)
+                eng.gate_batch_dev(R.NAND, full0.to(gpu), full1.to(gpu), ref, Gc, stream); eng.sync(stream)
+                differing = int((check[:Gc].to(gpu) != ref).any(dim=1).sum().item())
+                verdict[0] = differing
+                del ref
+            dist.broadcast(verdict, src=0)
+            if int(verdict.item()):
+                raise SystemExit("bench.py: SELF-CHECK FAILED before timing: %d gates of the sharded batch differ from rank 0's single-GPU batch; no line is printed"
+                                 % int(verdict.item()))
+        del check
         for _ in range(args.warmup):
             sg.run(R.NAND, full0, full1, total)
         barrier()
@@ -868,6 +907,7 @@ def run_rank(args):
         }
         if phase:
             line["phase_ms_per_step_rank0"] = phase
+            line["scatter_ms"], line["gather_ms"] = phase["scatter_ms_per_step"], phase["gather_ms_per_step"]      # per step, on rank 0's clock
         if mirror:
             # The ceiling that binds: FP64 vector issue with no FMA.  achieved = FP64-rate VALU lane-results per
             # second of the dominant kernel = counted wave-instructions per gate (structure of the transform, checked against
@@ -978,28 +1018,79 @@ def run_config3_c_abi(args):
     try:
         eng.load_bk_torus(bk)
         eng.load_ksk(ksk)
+        if args.backend == "ntt-exact":
+            eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        if args.backend == "split-fft-exact":
+            eng.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        # first contact between the devices happened in rtfhe_ctx_create_multi: say what the runtime reported, per entry
+        peers = [eng.peer_info(d) for d in range(1, len(devs))]
+        for d, i in enumerate(peers, 1):
+            sys.stderr.write("bench.py config3-c-abi: entry %d = device %d: %s; peer access primary->entry can %d enabled %d, entry->primary can %d enabled %d; "
+                             "link %s, %d hop(s)\n" % (d, i["device"], "SAME device as the primary (rehearsal on one card)" if i["same_device"] else "distinct device",
+                                                       i["can_access_from_primary"], i["enabled_from_primary"], i["can_access_to_primary"], i["enabled_to_primary"],
+                                                       i["link"], i["hops"]))
         rng = np.random.default_rng(3)
         b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
         d0 = torch.from_numpy(R.encrypt_bits(params, key0, b0, 1).view(np.int32)).to(gpu)
         d1 = torch.from_numpy(R.encrypt_bits(params, key0, b1, 2).view(np.int32)).to(gpu)
         do = torch.empty_like(d0)
         st = torch.cuda.current_stream().cuda_stream
+        # self-check before anything is timed: the sharded batch must be the single-device batch, word for word, on 2 x 8192 gates (the context's
+        # own primary as a one-device engine computes the reference; on distinct devices this is the first time peer copies and cross-device
+        # events carry real data)
+        selfcheck = None
+        if len(devs) > 1:
+            Gc = min(G, 2 * 8192)
+            one = R.Engine(params, devs[0])
+            try:
+                one.load_bk_torus(bk)
+                one.load_ksk(ksk)
+                one.set_backend(eng.backend())
+                ref = torch.empty_like(d0[:Gc])
+                one.gate_batch_dev(R.NAND, d0, d1, ref, Gc, st); one.sync(st)
+            finally:
+                one.close()
+            eng.gate_batch_dev(R.NAND, d0, d1, do, Gc, st); eng.sync(st)
+            differing = int((do[:Gc] != ref).any(dim=1).sum().item())
+            selfcheck = {"gates": Gc, "differing_gates": differing}
+            if differing:
+                first = int((do[:Gc] != ref).any(dim=1).nonzero()[0].item())
+                lo_hi = [R.shard_range(Gc, d, len(devs)) for d in range(len(devs))]
+                sys.stderr.write("bench.py config3-c-abi: SELF-CHECK FAILED before timing: %d of %d gates of the sharded batch differ from the single-device batch "
+                                 "(first at gate %d; shard ranges %s; peers %s) -- nothing was timed\n" % (differing, Gc, first, lo_hi, peers))
+                print(json.dumps({"metric": "HomNAND gates/sec (whole node), N=1024", "value": None, "ok": False, "selfcheck": selfcheck, "peers": peers}), flush=True)
+                return 3
+            del ref
         for _ in range(args.warmup):
             eng.gate_batch_dev(R.NAND, d0, d1, do, G, st)
         eng.sync(st)
+        phases = [[] for _ in peers]
         t0 = time.perf_counter()
         for _ in range(args.steps):
             eng.gate_batch_dev(R.NAND, d0, d1, do, G, st)
         eng.sync(st)
         elapsed = time.perf_counter() - t0
+        # the entries' phases of one more (untimed) step: pull from the primary, bootstrap, push back -- events on each entry's own stream
+        eng.gate_batch_dev(R.NAND, d0, d1, do, G, st); eng.sync(st)
+        for d in range(1, len(devs)):
+            i = eng.peer_info(d)
+            phases[d - 1] = {"entry": d, "device": i["device"], "scatter_ms": i["scatter_ms"], "compute_ms": i["compute_ms"], "gather_ms": i["gather_ms"]}
         ok = bool(np.array_equal(R.decrypt_bits(params, key0, do.cpu().numpy().view(np.uint32)), 1 - (b0 & b1)))
+        for ph in phases:
+            sys.stderr.write("bench.py config3-c-abi: entry %(entry)d (device %(device)d) per step: scatter %(scatter_ms)s ms, bootstrap %(compute_ms)s ms, gather %(gather_ms)s ms\n" % ph)
+        scat = [ph["scatter_ms"] for ph in phases if ph["scatter_ms"] is not None]
+        gath = [ph["gather_ms"] for ph in phases if ph["gather_ms"] is not None]
         print(json.dumps({"metric": "HomNAND gates/sec (whole node), N=1024", "value": round(G * args.steps / elapsed, 1), "unit": "gates/s",
                           "n_gpus": len(set(devs)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                           "config": {"workload": "batch of %d HomNAND gates resident on device %d, sharded over a multi-device CONTEXT of %d entries by "
                                                  "rtfhe_gate_batch_dev (C ABI; BASELINE configs[2])" % (G, devs[0], len(devs)),
-                                     "devices": devs, "device_bytes_per_entry": [eng.memory_bytes(d) for d in range(len(devs))]},
-                          "outputs_decrypt_correctly": ok}), flush=True)
+                                     "devices": devs, "backend": args.backend, "device_bytes_per_entry": [eng.memory_bytes(d) for d in range(len(devs))]},
+                          "scatter_ms": round(max(scat), 4) if scat else None, "gather_ms": round(max(gath), 4) if gath else None,
+                          "scatter_gather_is": "the slowest entry's pull of its inputs from / push of its outputs to the primary in one step (HIP events on the entry's own stream)",
+                          "entries": phases, "peers": peers, "selfcheck_before_timing": selfcheck,
+                          "outputs_decrypt_correctly": ok, "ok": bool(ok)}), flush=True)
+        return 0 if ok else 3
     finally:
         eng.close()
 
@@ -1030,7 +1121,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.workload == "config3-c-abi":
-        return run_config3_c_abi(args)
+        sys.exit(run_config3_c_abi(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args))                      # parent: spawn the ranks, never touch the GPU
     if "WORLD_SIZE" not in os.environ and not os.environ.get("RTFHE_BENCH_INNER") and not under_profiler():

@@ -13,6 +13,22 @@ pub struct rtfhe_params {
     pub ks_t: i32,       // key-switch levels      hom_nand/src/tlwe.rs:178
     pub ks_basebit: i32, // key-switch base bits   hom_nand/src/tlwe.rs:179
 }
+/// What the runtime reported about entry d of a multi-device context against the primary (include/rtfhe.h: rtfhe_peer_info).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct rtfhe_peer_info {
+    pub device: i32,
+    pub same_device: i32,
+    pub can_access_from_primary: i32,
+    pub can_access_to_primary: i32,
+    pub enabled_from_primary: i32,
+    pub enabled_to_primary: i32,
+    pub link_type: u32,
+    pub hops: u32,
+    pub scatter_ms: f32,
+    pub compute_ms: f32,
+    pub gather_ms: f32,
+}
 pub enum rtfhe_ctx {}
 pub enum rtfhe_circuit {}
 pub enum rtfhe_fft_plan {}
@@ -42,6 +58,8 @@ extern "C" {
     pub fn rtfhe_ctx_create_multi(p: *const rtfhe_params, device_ids: *const c_int, n_dev: c_int, out: *mut *mut rtfhe_ctx) -> c_int;
     pub fn rtfhe_ctx_device_count(ctx: *const rtfhe_ctx) -> c_int;
     pub fn rtfhe_ctx_memory_bytes(ctx: *const rtfhe_ctx, d: c_int, bytes: *mut usize) -> c_int;
+    pub fn rtfhe_ctx_peer_info(ctx: *mut rtfhe_ctx, d: c_int, out: *mut rtfhe_peer_info) -> c_int;
+    pub fn rtfhe_device_link(dev_a: c_int, dev_b: c_int, can_access: *mut i32, link_type: *mut u32, hops: *mut u32) -> c_int;
     pub fn rtfhe_shard_range(count: usize, d: c_int, n_dev: c_int, begin: *mut usize, end: *mut usize) -> c_int;
     pub fn rtfhe_host_alloc(bytes: usize) -> *mut c_void;
     pub fn rtfhe_host_free(p: *mut c_void);

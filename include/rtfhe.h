@@ -116,9 +116,34 @@ int rtfhe_ctx_create(const rtfhe_params *p, int device_id, rtfhe_ctx **out);
  * a full context of its own (stream, staging buffers, key replica). */
 int rtfhe_ctx_create_multi(const rtfhe_params *p, const int *device_ids, int n_dev, rtfhe_ctx **out);
 int rtfhe_ctx_device_count(const rtfhe_ctx *ctx);      /* devices behind this context (1 for rtfhe_ctx_create) */
-/* device memory entry d (0 = primary) of the context holds right now, in bytes: the keys in every layout built so far (second layouts of
- * the bootstrapping key are built by the first batch whose kernel shape reads them), tables, staging and scratch buffers */
+/* device memory entry d (0 = primary) of the context holds right now, in bytes: the keys in every form built so far (second layouts of
+ * the bootstrapping key are built by the first batch whose kernel shape reads them), staging and scratch buffers.  Not counted: the twiddle
+ * tables (a few hundred KiB) and the sample buffers of live circuits. */
 int rtfhe_ctx_memory_bytes(const rtfhe_ctx *ctx, int d, size_t *bytes);
+/* What the runtime reported about entry d (1 <= d < rtfhe_ctx_device_count) of a multi-device context against entry 0, the primary, when
+ * rtfhe_ctx_create_multi set it up -- peer access is queried in both directions and enabled explicitly there, never left to a first copy -- and
+ * how long that entry's share of the LAST device-resident sharded batch (rtfhe_gate_batch_dev / rtfhe_mux_batch_dev / rtfhe_bootstrap_batch_dev)
+ * took on its own stream.  Nothing here is assumed: a field says what a HIP call returned on this machine. */
+typedef struct rtfhe_peer_info {
+    int32_t device;                   /* HIP device id of entry d */
+    int32_t same_device;              /* 1: entry d names the primary's own device (a rehearsal on one card: no peer access involved) */
+    int32_t can_access_from_primary;  /* hipDeviceCanAccessPeer(primary -> entry d) */
+    int32_t can_access_to_primary;    /* hipDeviceCanAccessPeer(entry d -> primary) */
+    int32_t enabled_from_primary;     /* hipDeviceEnablePeerAccess on the primary for entry d's device succeeded (or was already in force) */
+    int32_t enabled_to_primary;       /* ... on entry d's device for the primary */
+    uint32_t link_type;               /* hipExtGetLinkTypeAndHopCount(primary, entry d): 1 HyperTransport, 2 QPI, 3 PCIe, 4 InfiniBand, 5 xGMI;
+                                       * 0xffffffff when the query failed or same_device */
+    uint32_t hops;
+    float scatter_ms;                 /* last sharded device-resident batch: entry d pulling its range of the inputs from the primary, */
+    float compute_ms;                 /* bootstrapping it, */
+    float gather_ms;                  /* pushing its outputs into the caller's buffer on the primary; -1 when there was no such batch yet,
+                                       * the entry had no gates in it, or it has not completed (call rtfhe_sync first) */
+} rtfhe_peer_info;
+int rtfhe_ctx_peer_info(rtfhe_ctx *ctx, int d, rtfhe_peer_info *out);
+/* the same questions about any two devices of the node, without a context (a one-process-per-GPU job prints this per rank): *can_access =
+ * hipDeviceCanAccessPeer(dev_a -> dev_b), *link_type / *hops = hipExtGetLinkTypeAndHopCount (0xffffffff / 0 when the query fails).  Queries
+ * only: nothing is enabled. */
+int rtfhe_device_link(int dev_a, int dev_b, int32_t *can_access, uint32_t *link_type, uint32_t *hops);
 /* the range [*begin, *end) of a `count`-gate host batch that entry d of an n_dev-device context bootstraps (no GPU needed) */
 int rtfhe_shard_range(size_t count, int d, int n_dev, size_t *begin, size_t *end);
 void rtfhe_ctx_destroy(rtfhe_ctx *ctx);
@@ -150,7 +175,13 @@ int rtfhe_twiddles_write(const rtfhe_ctx *ctx, const char *path);
 int rtfhe_twiddles_file_write(const char *path, int32_t N, const double *ifft_table, const double *fft_table);
 int rtfhe_twiddles_file_read(const char *path, int32_t N, double *ifft_table, double *fft_table);
 
-/* ---- keys ---- */
+/* ---- keys ----
+ * Loading a bootstrapping key (or new twiddle tables under a torus-form key) into a context that already holds one replaces it IN PLACE: the
+ * spectra and every further form of the key that has been built (second kernel layouts, the exact backends' forms) are rebuilt in their
+ * existing buffers before the call returns, on every device of the context.  A recorded circuit, or a capture the caller took around a *_dev
+ * call, therefore replays against the new key.  One exception: a key given as spectra (rtfhe_load_bk_fft) has no torus form, the exact
+ * backends' forms cannot follow it, and circuits recorded on those backends fail with RTFHE_ERR_STATE from then on (record them again after
+ * loading a torus-form key); a caller's own capture of an exact-backend batch must be retaken in that case. */
 int rtfhe_load_bk_torus(rtfhe_ctx *ctx, const uint32_t *bk /* [n][2][2l][N] */);
 int rtfhe_load_bk_fft(rtfhe_ctx *ctx, const double *bk_f /* [n][2][2l][N] */);
 int rtfhe_export_bk_fft(rtfhe_ctx *ctx, double *bk_f /* [n][2][2l][N] */);
@@ -169,7 +200,12 @@ int rtfhe_bootstrap_batch(rtfhe_ctx *ctx, const uint32_t *tlwe, uint32_t *out, s
 int rtfhe_gate_batch_dev(rtfhe_ctx *ctx, int op, const void *d_in0, const void *d_in1, void *d_out,
                          size_t count, void *stream);
 int rtfhe_mux_batch_dev(rtfhe_ctx *ctx, const void *d_c, const void *d_in0, const void *d_in1, void *d_out,
-                        size_t count, void *stream);          /* d_out may alias none of the inputs */
+                        size_t count, void *stream);          /* d_out may alias none of the inputs.  The two intermediate batches live
+                                                                 * in buffers of the context that belong to `stream` (MUX batches on different
+                                                                 * streams may overlap).  Inside a caller's stream capture the call succeeds only
+                                                                 * if an eager MUX batch of at least `count` gates ran on that stream before
+                                                                 * (nothing may be allocated inside a capture): RTFHE_ERR_STATE otherwise; the
+                                                                 * buffers a capture used are then kept until the context is destroyed. */
 int rtfhe_bootstrap_batch_dev(rtfhe_ctx *ctx, const void *d_tlwe, void *d_out, size_t count, void *stream);
 /* one dependency wave of a gate netlist (the build-side counterpart of nander's eager tree walk, nander/src/lib.rs:72-89):
  * gate g reads rows idx0[g] and idx1[g] of the wire table d_wires (u32[num_wires][n+1]), applies ops[g] and writes row

@@ -29,6 +29,22 @@ class Params(C.Structure):
         return self.N * self.ks_t * ((1 << self.ks_basebit) - 1) * (self.n + 1)
 
 
+class PeerInfo(C.Structure):
+    """rtfhe_peer_info: what the runtime reported about entry d of a multi-device context against the primary (include/rtfhe.h)."""
+    _fields_ = [("device", C.c_int32), ("same_device", C.c_int32), ("can_access_from_primary", C.c_int32), ("can_access_to_primary", C.c_int32),
+                ("enabled_from_primary", C.c_int32), ("enabled_to_primary", C.c_int32), ("link_type", C.c_uint32), ("hops", C.c_uint32),
+                ("scatter_ms", C.c_float), ("compute_ms", C.c_float), ("gather_ms", C.c_float)]
+
+    LINK_NAMES = {1: "HyperTransport", 2: "QPI", 3: "PCIe", 4: "InfiniBand", 5: "xGMI", 0xFFFFFFFF: "not reported"}
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["link"] = self.LINK_NAMES.get(self.link_type, "type %d" % self.link_type)
+        for k in ("scatter_ms", "compute_ms", "gather_ms"):
+            d[k] = None if d[k] < 0 else round(d[k], 4)
+        return d
+
+
 NAND, AND, OR, XOR, NOT, COPY, ANDNY = range(7)
 BACKEND_FFT64_MIRROR, BACKEND_NTT_EXACT, BACKEND_FFT_SPLIT_EXACT = 0, 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
@@ -40,6 +56,8 @@ _SIGNATURES = {
     "rtfhe_ctx_create_multi": (C.c_int, ["PP", C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "rtfhe_ctx_device_count": (C.c_int, [C.c_void_p]),
     "rtfhe_ctx_memory_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "rtfhe_ctx_peer_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PeerInfo)]),
+    "rtfhe_device_link": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rtfhe_ctx_destroy": (None, [C.c_void_p]),
     "rtfhe_host_alloc": (C.c_void_p, [C.c_size_t]),
     "rtfhe_host_free": (None, [C.c_void_p]),

@@ -88,22 +88,42 @@ int run_host_bootstrap_one(rtfhe_ctx* ctx, int op, int mode, int steps, const ui
 }
 
 // hom_mux (tfhe.rs:27-40): i1 = AND(c, in1); i0 = AND(-c, in0); bootstrap(i1 + i0 + 1/8) -- the last line is hom_or(i1, i0).
-// Three launches back to back on stream s with i1 / i0 kept in the context's own device buffers.
+// Three launches back to back on stream s with i1 / i0 kept in the context's own device buffers OF THAT STREAM (advisor r5: one pair shared by
+// every stream let two overlapping MUX batches overwrite each other's intermediates).  Inside a caller's stream capture nothing may be
+// allocated or synchronised: the call goes through only if this stream's pair already holds the batch (run one eager MUX batch of at least this
+// size on the stream first) -- and that pair is then kept for as long as the context lives, because the graph owns its addresses.
 int mux_dev_one(rtfhe_ctx* ctx, const void* d_c, const void* d_in0, const void* d_in1, void* d_out, size_t count, hipStream_t s) {
     if (int rc = use(ctx)) return rc;
     if (count == 0) return 0;
     const size_t bytes = count * ((size_t)ctx->p.n + 1) * 4;
-    if (ctx->cap_mux < bytes) {
-        HIPCHECK(ctx, hipDeviceSynchronize());            // earlier MUX batches may still read the old intermediates
-        for (void*& m : ctx->h_mux) { if (m) HIPCHECK(ctx, hipFree(m)); m = nullptr; }
-        ctx->cap_mux = 0;
-        for (void*& m : ctx->h_mux) HIPCHECK(ctx, hipMalloc(&m, bytes));
-        ctx->cap_mux = bytes;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    auto it = ctx->mux.find(s);
+    if (capturing) {
+        if (it == ctx->mux.end() || it->second.cap < bytes)
+            return fail(ctx, RTFHE_ERR_STATE, "a MUX batch inside a stream capture needs this stream's intermediate buffers to exist already: run one eager MUX batch of "
+                                              "at least this many gates on the stream before capturing");
+        it->second.captured = true;
+    } else if (it == ctx->mux.end() || it->second.cap < bytes) {
+        rtfhe_ctx::MuxBuf& mb = ctx->mux[s];
+        HIPCHECK(ctx, hipDeviceSynchronize());            // earlier MUX batches of this stream may still read the old intermediates
+        for (void*& m : mb.m) {
+            if (m && mb.captured) ctx->mux_retired.push_back(m);      // a graph holds its address: kept until the context goes
+            else if (m) HIPCHECK(ctx, hipFree(m));
+            m = nullptr;
+        }
+        mb.cap = 0; mb.captured = false;
+        for (void*& m : mb.m) HIPCHECK(ctx, hipMalloc(&m, bytes));
+        mb.cap = bytes;
+        it = ctx->mux.find(s);
     }
+    void* const i1 = it->second.m[0];
+    void* const i0 = it->second.m[1];
     const int n = ctx->p.n;
-    if (int rc = launch_bootstrap(ctx, RTFHE_AND, MODE_GATE, n, d_c, d_in1, ctx->h_mux[0], count, s)) return rc;     // i1
-    if (int rc = launch_bootstrap(ctx, RTFHE_ANDNY, MODE_GATE, n, d_c, d_in0, ctx->h_mux[1], count, s)) return rc;   // i0
-    return launch_bootstrap(ctx, RTFHE_OR, MODE_GATE, n, ctx->h_mux[0], ctx->h_mux[1], d_out, count, s);
+    if (int rc = launch_bootstrap(ctx, RTFHE_AND, MODE_GATE, n, d_c, d_in1, i1, count, s)) return rc;
+    if (int rc = launch_bootstrap(ctx, RTFHE_ANDNY, MODE_GATE, n, d_c, d_in0, i0, count, s)) return rc;
+    return launch_bootstrap(ctx, RTFHE_OR, MODE_GATE, n, i1, i0, d_out, count, s);
 }
 
 // ... with host buffers: one copy in (c, in0, in1), the three launches on the context's stream, one copy out

@@ -58,7 +58,7 @@ int rtfhe_circuit_create(rtfhe_ctx* ctx, const void* d_ops, const void* d_idx0, 
     }
     rtfhe_circuit* c = new (std::nothrow) rtfhe_circuit();
     if (!c) { if (cbuf.d) (void)hipFree(cbuf.d); return fail(ctx, RTFHE_ERR_NOMEM, "out of host memory"); }
-    c->ctx = ctx; c->device = ctx->device; c->waves = num_waves; c->d_samples = cbuf.d;
+    c->ctx = ctx; c->device = ctx->device; c->waves = num_waves; c->d_samples = cbuf.d; c->backend = ctx->backend;
     const int64_t before = ctx->launches;
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { circuit_release(c); delete c; return fail(ctx, RTFHE_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); }
@@ -90,6 +90,8 @@ int rtfhe_circuit_launch(rtfhe_circuit* c, void* stream) {
     if (!c->ctx) return fail(nullptr, RTFHE_ERR_STATE, "the circuit's context has been destroyed");
     rtfhe_ctx* ctx = c->ctx;
     if (int rc = use(ctx)) return rc;
+    if (c->stale) return fail(ctx, RTFHE_ERR_STATE, "the circuit was recorded on an exact backend and the bootstrapping key has since been replaced by one without a "
+                                                  "torus form (rtfhe_load_bk_fft): its key form could not follow; record the circuit again");
     HIPCHECK(ctx, hipGraphLaunch(c->exec, (hipStream_t)stream));
     ctx->launches += c->launches;
     return 0;

@@ -40,7 +40,8 @@ int transform_bk_from_torus(rtfhe_ctx* ctx) {
     return 0;
 }
 
-// a new key (or new tables under a torus-form key): whatever was derived from the old spectra is stale
+// a new key (or new tables under a torus-form key): whatever was derived from the old spectra is stale -- and, where its buffer exists, is
+// rebuilt at once by the caller (rebuild_derived_keys, rtfhe_dispatch_fft.hip)
 void key_changed(rtfhe_ctx* ctx) {
     ctx->ebk_valid = false; ctx->p4bk_valid = false; ctx->ntt_ready = false; ctx->xfft_ready = false;
 }
@@ -196,8 +197,8 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
     if (!rc && (hipMalloc((void**)&ctx->d_fault, 4) != hipSuccess || hipMemset(ctx->d_fault, 0, 4) != hipSuccess))
         rc = fail(ctx, RTFHE_ERR_HIP, "hipMalloc failed");
     if (!rc && hipStreamCreate(&ctx->stream) != hipSuccess) rc = fail(ctx, RTFHE_ERR_HIP, "hipStreamCreate failed");
-    if (!rc && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-                hipEventCreateWithFlags(&ctx->ev_shard, hipEventDisableTiming) != hipSuccess))
+    if (!rc && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev_shard) != hipSuccess ||
+                hipEventCreate(&ctx->ev_sh[0]) != hipSuccess || hipEventCreate(&ctx->ev_sh[1]) != hipSuccess || hipEventCreate(&ctx->ev_sh[2]) != hipSuccess))
         rc = fail(ctx, RTFHE_ERR_HIP, "hipEventCreate failed");
     if (rc) { g_last_error = ctx->err; rtfhe_ctx_destroy(ctx); return rc; }
 #ifdef RTFHE_WG_STAMPS
@@ -223,15 +224,63 @@ int rtfhe_ctx_create_multi(const rtfhe_params* p, const int* device_ids, int n_d
         rtfhe_ctx* peer = nullptr;
         if (int rc = create_single(p, device_ids[d], &peer)) { rtfhe_ctx_destroy(ctx); return rc; }
         ctx->peers.push_back(peer);
+        // First contact between the two devices happens HERE, explicitly, and what the runtime answers is kept (rtfhe_ctx_peer_info): whether each
+        // may address the other's memory, whether enabling that worked, and what link the runtime reports between them.  A copy between devices
+        // without peer access is staged through host memory by the runtime -- correct, and several times slower than the xGMI path the design
+        // expects; the context works either way and says which it got.
+        rtfhe_ctx::PeerLink& k = peer->link;
+        if (peer->device == ctx->device) { k.same_device = 1; continue; }
+        auto enable = [&](int from, int to) {
+            if (hipSetDevice(from) != hipSuccess) { (void)hipGetLastError(); return 0; }
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            (void)hipGetLastError();
+            return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+        };
+        if (hipDeviceCanAccessPeer(&k.can_from, ctx->device, peer->device) != hipSuccess) { (void)hipGetLastError(); k.can_from = 0; }
+        if (hipDeviceCanAccessPeer(&k.can_to, peer->device, ctx->device) != hipSuccess) { (void)hipGetLastError(); k.can_to = 0; }
+        if (k.can_from) k.en_from = enable(ctx->device, peer->device);
+        if (k.can_to) k.en_to = enable(peer->device, ctx->device);
+        uint32_t lt = 0, hops = 0;
+        if (hipExtGetLinkTypeAndHopCount(ctx->device, peer->device, &lt, &hops) == hipSuccess) { k.link_type = lt; k.hops = hops; }
+        else (void)hipGetLastError();
     }
     (void)hipSetDevice(ctx->device);
     *out = ctx;
     return 0;
 }
 
+int rtfhe_device_link(int dev_a, int dev_b, int32_t* can_access, uint32_t* link_type, uint32_t* hops) {
+    if (!can_access || !link_type || !hops) return fail(nullptr, RTFHE_ERR_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(nullptr, RTFHE_ERR_NO_DEVICE, "no HIP device available"); }
+    if (dev_a < 0 || dev_a >= ndev || dev_b < 0 || dev_b >= ndev || dev_a == dev_b) return fail(nullptr, RTFHE_ERR_INVALID, "rtfhe_device_link: two distinct device ids of this node");
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev_a, dev_b) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+    *can_access = can; *link_type = 0xffffffffu; *hops = 0;
+    uint32_t lt = 0, h = 0;
+    if (hipExtGetLinkTypeAndHopCount(dev_a, dev_b, &lt, &h) == hipSuccess) { *link_type = lt; *hops = h; }
+    else (void)hipGetLastError();
+    return 0;
+}
+
+int rtfhe_ctx_peer_info(rtfhe_ctx* ctx, int d, rtfhe_peer_info* out) {
+    if (!ctx || !out || d < 1 || d > (int)ctx->peers.size()) return fail(ctx, RTFHE_ERR_INVALID, "rtfhe_ctx_peer_info: entry out of range (1 <= d < device count)");
+    rtfhe_ctx* peer = ctx->peers[d - 1];
+    const rtfhe_ctx::PeerLink& k = peer->link;
+    *out = rtfhe_peer_info{peer->device, k.same_device, k.can_from, k.can_to, k.en_from, k.en_to, k.link_type, k.hops, -1.f, -1.f, -1.f};
+    if (peer->shard_timed && hipEventQuery(peer->ev_shard) == hipSuccess) {
+        float a = -1.f, b = -1.f, c = -1.f;
+        if (hipEventElapsedTime(&a, peer->ev_sh[0], peer->ev_sh[1]) == hipSuccess && hipEventElapsedTime(&b, peer->ev_sh[1], peer->ev_sh[2]) == hipSuccess &&
+            hipEventElapsedTime(&c, peer->ev_sh[2], peer->ev_shard) == hipSuccess) { out->scatter_ms = a; out->compute_ms = b; out->gather_ms = c; }
+    }
+    (void)hipGetLastError();
+    return 0;
+}
+
 int rtfhe_ctx_device_count(const rtfhe_ctx* ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
 
-// device memory entry d of the context holds right now: keys in every layout built so far, tables, staging and scratch
+// device memory entry d of the context holds right now: the keys in every form built so far, staging and scratch buffers (not the twiddle tables,
+// a few hundred KiB, nor the sample buffers of live circuits)
 int rtfhe_ctx_memory_bytes(const rtfhe_ctx* ctx, int d, size_t* bytes) {
     if (!ctx || !bytes || d < 0 || d > (int)ctx->peers.size()) return fail(nullptr, RTFHE_ERR_INVALID, "rtfhe_ctx_memory_bytes: bad argument");
     const rtfhe_ctx* c = d == 0 ? ctx : ctx->peers[d - 1];
@@ -246,7 +295,8 @@ int rtfhe_ctx_memory_bytes(const rtfhe_ctx* ctx, int d, size_t* bytes) {
     if (c->d_ksk) b += c->ksk_bytes;
     if (c->d_ksmat) b += c->ksmat_bytes;
     for (const auto& kv : c->tlwe1) b += kv.second.cap * ((size_t)c->p.N + 1) * 4;
-    b += c->cap_a + c->cap_b + c->cap_c + 2 * c->cap_mux;
+    b += c->cap_a + c->cap_b + c->cap_c;
+    for (const auto& kv : c->mux) b += 2 * kv.second.cap;
     *bytes = b;
     return 0;
 }
@@ -297,11 +347,13 @@ void rtfhe_ctx_destroy(rtfhe_ctx* ctx) {
     if (ctx->d_b) (void)hipFree(ctx->d_b);
     if (ctx->d_c) (void)hipFree(ctx->d_c);
     for (void* h : ctx->h_pin) if (h) (void)hipHostFree(h);
-    for (void* m : ctx->h_mux) if (m) (void)hipFree(m);
+    for (auto& kv : ctx->mux) for (void* m : kv.second.m) if (m) (void)hipFree(m);
+    for (void* m : ctx->mux_retired) (void)hipFree(m);
     for (hipEvent_t e : ctx->ks_events) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
+    for (hipEvent_t e : ctx->ev_sh) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -342,6 +394,7 @@ int rtfhe_set_twiddles(rtfhe_ctx* ctx, const double* ifft_table, const double* f
     if (ctx->has_bk && ctx->d_bk_torus) {
         if (int rc = transform_bk_from_torus(ctx)) return rc;
         key_changed(ctx);
+        if (int rc = rebuild_derived_keys(ctx)) return rc;
     }
     for (rtfhe_ctx* peer : ctx->peers) {
         if (int rc = rtfhe_set_twiddles(peer, ifft_table, fft_table)) return fail(ctx, rc, peer->err);
@@ -388,11 +441,14 @@ int rtfhe_load_bk_torus(rtfhe_ctx* ctx, const uint32_t* bk) {
     if (int rc = transform_bk_from_torus(ctx)) return rc;
     key_changed(ctx);
     ctx->has_bk = true;
+    if (int rc = rebuild_derived_keys(ctx)) return rc;
     for (rtfhe_ctx* peer : ctx->peers) {      // the transformed key and its torus form, device to device
         if (int rc = replicate(ctx, peer, ctx->d_bk, (void**)&peer->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx))) return rc;
         if (int rc = replicate(ctx, peer, ctx->d_bk_torus, (void**)&peer->d_bk_torus, words * 4)) return rc;
         key_changed(peer); peer->has_bk = true;
+        if (int rc = rebuild_derived_keys(peer)) return fail(ctx, rc, peer->err);
     }
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
     return 0;
 }
 
@@ -409,11 +465,14 @@ int rtfhe_load_bk_fft(rtfhe_ctx* ctx, const double* bk_f) {
     if (ctx->d_bk_torus) { (void)hipFree(ctx->d_bk_torus); ctx->d_bk_torus = nullptr; }   // no torus form of this key
     key_changed(ctx);
     ctx->has_bk = true;
+    if (int rc = rebuild_derived_keys(ctx)) return rc;
     for (rtfhe_ctx* peer : ctx->peers) {
         if (int rc = replicate(ctx, peer, ctx->d_bk, (void**)&peer->d_bk, bk_cplx_count(ctx->p) * sizeof(cplx))) return rc;
         if (peer->d_bk_torus) { (void)hipSetDevice(peer->device); (void)hipFree(peer->d_bk_torus); peer->d_bk_torus = nullptr; (void)hipSetDevice(ctx->device); }
         key_changed(peer); peer->has_bk = true;
+        if (int rc = rebuild_derived_keys(peer)) return fail(ctx, rc, peer->err);
     }
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
     return 0;
 }
 

@@ -243,19 +243,44 @@ int launch_bootstrap_fft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
 // The key spectra once more in the layout a kernel family reads (derived from d_bk on this context's device), built by the first batch whose
 // dispatch needs it -- a context that never runs such a batch never pays for the copy (N = 2048: 125 MB, N = 1024: 62 MB).  Called outside
 // stream captures only (it allocates and synchronises); a dispatch inside a capture that finds the layout absent takes the kernels that read d_bk.
-int ensure_bk_layouts(rtfhe_ctx* ctx, size_t count, int mode) {
-    const int need = layout_needed(ctx, count, mode);
-    if (need == LAYOUT_NONE || !ctx->d_bk) return 0;
-    cplx** dst = need == LAYOUT_EO ? &ctx->d_ebk : &ctx->d_p4bk;
-    bool* valid = need == LAYOUT_EO ? &ctx->ebk_valid : &ctx->p4bk_valid;
-    if (*valid) return 0;
+static int build_bk_layout(rtfhe_ctx* ctx, int which) {
+    cplx** dst = which == LAYOUT_EO ? &ctx->d_ebk : &ctx->d_p4bk;
+    bool* valid = which == LAYOUT_EO ? &ctx->ebk_valid : &ctx->p4bk_valid;
     const size_t polys = bk_word_count(ctx->p) / ctx->p.N;
     if (!*dst) HIPCHECK(ctx, hipMalloc((void**)dst, bk_cplx_count(ctx->p) * sizeof(cplx)));
-    if (need == LAYOUT_EO) hipLaunchKernelGGL(k_bk_to_eo, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, *dst, polys);
+    if (which == LAYOUT_EO) hipLaunchKernelGGL(k_bk_to_eo, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, *dst, polys);
     else hipLaunchKernelGGL(k_bk_to_p4, dim3(2048), dim3(256), 0, ctx->stream, (const cplx*)ctx->d_bk, *dst, polys);
     HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     *valid = true;
+    return 0;
+}
+
+int ensure_bk_layouts(rtfhe_ctx* ctx, size_t count, int mode) {
+    const int need = layout_needed(ctx, count, mode);
+    if (need == LAYOUT_NONE || !ctx->d_bk) return 0;
+    if (need == LAYOUT_EO ? ctx->ebk_valid : ctx->p4bk_valid) return 0;
+    return build_bk_layout(ctx, need);
+}
+
+// A new key has just been put into d_bk (and d_bk_torus): every derived form of the key whose BUFFER ALREADY EXISTS is rebuilt in place, now,
+// synchronously.  Such a buffer's address may be baked into a HIP graph -- one of this context's circuits, or a capture the caller took around a
+// *_dev call -- and a replay must find the new key there, not the old key's spectra until some later eager batch happens to rebuild them
+// (advisor r5).  Forms that were never built stay unbuilt (built on demand, ensure_bk_layouts / ntt_prepare / xfft_prepare).  The exact backends'
+// forms derive from the torus form of the key: a key that came as spectra (rtfhe_load_bk_fft) has none, the old forms cannot be rebuilt, and
+// the circuits recorded on those backends are marked stale (rtfhe_circuit_launch then fails with RTFHE_ERR_STATE instead of computing with
+// the old key).
+int rebuild_derived_keys(rtfhe_ctx* ctx) {
+    if (int rc = use(ctx)) return rc;
+    if (ctx->d_ebk) if (int rc = build_bk_layout(ctx, LAYOUT_EO)) return rc;
+    if (ctx->d_p4bk) if (int rc = build_bk_layout(ctx, LAYOUT_P4)) return rc;
+    if (ctx->d_bk_torus) {
+        if (ctx->d_ntt_bk) if (int rc = ntt_prepare(ctx)) return rc;
+        if (ctx->d_xbk) if (int rc = xfft_prepare(ctx)) return rc;
+    } else if (ctx->d_ntt_bk || ctx->d_xbk) {
+        for (rtfhe_circuit* c : ctx->circuits)
+            if (c->backend != RTFHE_BACKEND_FFT64_MIRROR) c->stale = true;
+    }
     return 0;
 }
 

@@ -93,6 +93,10 @@ struct rtfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_shard = nullptr;    // multi-device, device-resident batches: "inputs ready" on the primary / "shard gathered" on a peer
+    hipEvent_t ev_sh[3] = {nullptr, nullptr, nullptr};   // a peer's share of such a batch: before its pull, after it, after its bootstrap (ev_shard: after its push)
+    bool shard_timed = false;         // ev_sh / ev_shard bracket a batch
+    // what rtfhe_ctx_create_multi found out about this entry against the primary (rtfhe_ctx_peer_info)
+    struct PeerLink { int same_device = 0, can_from = 0, can_to = 0, en_from = 0, en_to = 0; uint32_t link_type = 0xffffffffu, hops = 0; } link;
     int64_t launches = 0;
     // between rtfhe_timer_begin and _end every batch key switch of the split path is bracketed by a pair of events of its own, so
     // that the timer can report the blind-rotation kernel's and the key-switch kernel's device time separately
@@ -106,8 +110,12 @@ struct rtfhe_ctx {
     // the set.  Keys are loaded once on this context and copied device-to-device; batches are sharded (rtfhe_multi.hip).
     std::vector<rtfhe_ctx*> peers;
     std::vector<rtfhe_circuit*> circuits;   // live HIP-graph circuits of this context: orphaned (not freed) by rtfhe_ctx_destroy
-    void* h_mux[2] = {nullptr, nullptr};   // device intermediates of a MUX batch
-    size_t cap_mux = 0;
+    // device intermediates (i1, i0) of a MUX batch: one pair per stream a MUX batch was ever launched on, as the lvl1 samples above (two MUX
+    // batches on different streams of one context may overlap).  A pair whose addresses went into a caller's capture is never freed or replaced
+    // while the context lives (`captured`): a later, larger eager batch on that stream gets a new pair and the old one moves to mux_retired.
+    struct MuxBuf { void* m[2] = {nullptr, nullptr}; size_t cap = 0; bool captured = false; };
+    std::unordered_map<hipStream_t, MuxBuf> mux;
+    std::vector<void*> mux_retired;
     int num_cus = 256;
     int force_waves = 0;   // RTFHE_FORCE_WAVES=1|2|4|8: one kernel shape for every batch (the parity tests' second opinions)
     int wg_max = 512;      // RTFHE_WG_MAX_GATES: largest batch routed to the workgroup-per-gate kernel
@@ -123,6 +131,8 @@ struct rtfhe_circuit {
     uint32_t* d_samples = nullptr;   // the circuit's own lvl1 sample buffer (split path): replays on any stream never share one with other work
     int32_t waves = 0;
     int64_t launches = 0;      // kernel launches one replay stands for
+    int backend = RTFHE_BACKEND_FFT64_MIRROR;   // the backend it was recorded on
+    bool stale = false;        // recorded on an exact backend whose key form could not follow a key change (rebuild_derived_keys)
 };
 
 namespace rtfhe_host {
@@ -168,6 +178,7 @@ int prime_fft_kernels(rtfhe_ctx* ctx);                                    // gra
 int launch_bootstrap_fft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s);
 // builds (outside any stream capture) the second key layouts the dispatch of a `count`-gate batch in `mode` will read; no-op when they stand
 int ensure_bk_layouts(rtfhe_ctx* ctx, size_t count, int mode);
+int rebuild_derived_keys(rtfhe_ctx* ctx);                               // after a key change: every derived key form that already exists, in place, now
 
 // ---- exact-integer NTT backend (rtfhe_dispatch_ntt.hip) ----
 int prime_ntt_kernels(rtfhe_ctx* ctx);

@@ -73,14 +73,21 @@ int sharded_host_mux(rtfhe_ctx* ctx, const uint32_t* c, const uint32_t* in0, con
 // returns without synchronising (the semantics of every *_dev call).  In stream order of the caller's stream s on the primary:
 //   1. an event marks "the inputs are ready";
 //   2. the primary's OWN range is launched on s right behind it -- the primary never waits for anything before it computes;
-//   3. every peer, on its own stream: waits for the event, pulls its range of the inputs into its staging buffers (hipMemcpyPeerAsync, peer pulls),
-//      bootstraps it, pushes the outputs into the caller's output buffer on the primary, records its own event;
+//   3. every peer, on its own stream: waits for the event, pulls its range of the inputs into its staging buffers, bootstraps it, pushes the outputs
+//      into the caller's output buffer on the primary, records its own event (and three more in between: rtfhe_ctx_peer_info reports the phases);
 //   4. s waits for the peers' events: whatever the caller enqueues on s next sees all outputs (and may overwrite the inputs).
-// The copies are hipMemcpyPeerAsync, i.e. the copy engines (SDMA over xGMI), not kernels: the bootstrap kernels need every CU of a device at one
-// workgroup per CU (__launch_bounds__(512, 1), LDS-full), and a copy KERNEL that still holds a CU when a bootstrap launch starts makes one
-// workgroup wait a whole round for it -- the send side of an RCCL send/recv pair has exactly that hazard on the root; an SDMA copy holds no CU.
+// The copies are hipMemcpyPeerAsync between device memory of the primary and of the peer -- EXPECTED to run on the copy engines (SDMA over xGMI)
+// once peer access is in force, which rtfhe_ctx_create_multi enables explicitly and reports; UNVERIFIED: this path has only ever run with every
+// entry naming one card (same-device copies).  The reason for wanting copy engines rather than copy kernels: the bootstrap kernels need every CU
+// of a device at one workgroup per CU (__launch_bounds__(512, 1), LDS-full), and a copy KERNEL that still holds a CU when a bootstrap launch
+// starts makes one workgroup wait a whole round for it -- the send side of an RCCL send/recv pair has exactly that hazard on the root.  Without
+// peer access the runtime stages such a copy through host memory: still correct, and scatter_ms / gather_ms will show it.  Batch pointers that are
+// not device memory of the primary (pinned host, managed, another GPU's memory: all admitted by gpu_accessible) are copied with
+// hipMemcpyAsync(hipMemcpyDefault) instead, which lets the runtime find out where they live.
 // Volumes are negligible next to the compute (config 3: 65,536 gates = 333 MB in, 167 MB out against 53 ms of bootstrapping per 8,192 gates).
 // Inside a stream capture on s the whole batch stays on the primary (the staging buffers of a peer are not the capture's to bake in).
+// A failure part-way leaves nothing dangling: s still waits for every peer already launched (they may be writing d_out), the current device is
+// the primary's again, and the first error is what the call returns.
 int sharded_dev_batch(rtfhe_ctx* ctx, int op, const void* d_c, const void* d_in0, const void* d_in1, void* d_out, size_t count, hipStream_t s) {
     if (int rc = use(ctx)) return rc;
     const bool mux = op < 0;
@@ -95,39 +102,79 @@ int sharded_dev_batch(rtfhe_ctx* ctx, int op, const void* d_c, const void* d_in0
     const int n_dev = 1 + (int)ctx->peers.size();
     const size_t w = (size_t)ctx->p.n + 1;
     auto at = [&](const void* p, size_t gate) { return p ? (const void*)((const uint32_t*)p + gate * w) : nullptr; };
+    // is p device memory of the primary?  (only then may hipMemcpyPeerAsync be told so)
+    auto on_primary = [&](const void* p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeDevice && a.device == ctx->device;
+    };
+    const bool peer_copies = on_primary(d_in0) && (!d_in1 || on_primary(d_in1)) && (!d_c || on_primary(d_c)) && on_primary(d_out);
     // staging of every peer first (it may allocate, i.e. synchronise a device), then nothing but asynchronous calls
     for (int d = 1; d < n_dev; d++) {
         rtfhe_ctx* peer = ctx->peers[d - 1];
+        peer->shard_timed = false;
         const size_t bytes = (shard_begin(count, d + 1, n_dev) - shard_begin(count, d, n_dev)) * w * 4;
         if (!bytes) continue;
-        if (int rc = use(peer)) return fail(ctx, rc, peer->err);
-        if (int rc = ensure(peer, &peer->d_a, &peer->cap_a, bytes)) return fail(ctx, rc, peer->err);
-        if (d_in1 || mux) if (int rc = ensure(peer, &peer->d_b, &peer->cap_b, bytes)) return fail(ctx, rc, peer->err);
-        if (int rc = ensure(peer, &peer->d_c, &peer->cap_c, bytes)) return fail(ctx, rc, peer->err);
+        int rc = use(peer);
+        if (!rc) rc = ensure(peer, &peer->d_a, &peer->cap_a, bytes);
+        if (!rc && (d_in1 || mux)) rc = ensure(peer, &peer->d_b, &peer->cap_b, bytes);
+        if (!rc) rc = ensure(peer, &peer->d_c, &peer->cap_c, bytes);
+        if (rc) { (void)hipSetDevice(ctx->device); return fail(ctx, rc, peer->err); }
     }
     if (int rc = use(ctx)) return rc;
     HIPCHECK(ctx, hipEventRecord(ctx->ev_shard, s));
     if (const size_t own = shard_begin(count, 1, n_dev))
         if (int rc = run(ctx, d_c, d_in0, d_in1, d_out, own, s)) return rc;
-    for (int d = 1; d < n_dev; d++) {
+    // from here on an error may not return before s has been made to wait for the peers already launched
+    int first_rc = 0;
+    std::string first_err;
+    std::vector<rtfhe_ctx*> launched;
+    auto pull = [&](rtfhe_ctx* peer, void* dst, const void* src, size_t bytes) {
+        return peer_copies ? hipMemcpyPeerAsync(dst, peer->device, src, ctx->device, bytes, peer->stream) : hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, peer->stream);
+    };
+    for (int d = 1; d < n_dev && !first_rc; d++) {
         rtfhe_ctx* peer = ctx->peers[d - 1];
         const size_t b = shard_begin(count, d, n_dev), cnt = shard_begin(count, d + 1, n_dev) - b, bytes = cnt * w * 4;
         if (!cnt) continue;
-        if (int rc = use(peer)) return fail(ctx, rc, peer->err);
-        HIPCHECK(ctx, hipStreamWaitEvent(peer->stream, ctx->ev_shard, 0));
+        auto hip = [&](hipError_t e, const char* what) {
+            if (e == hipSuccess || first_rc) return e == hipSuccess;
+            (void)hipGetLastError();
+            first_rc = RTFHE_ERR_HIP;
+            first_err = std::string(what) + " on device " + std::to_string(peer->device) + ": " + hipGetErrorString(e);
+            return false;
+        };
+        if (!hip(hipSetDevice(peer->device), "hipSetDevice")) break;
+        if (!hip(hipStreamWaitEvent(peer->stream, ctx->ev_shard, 0), "hipStreamWaitEvent")) break;
+        bool ok = hip(hipEventRecord(peer->ev_sh[0], peer->stream), "hipEventRecord");
         // gate batch: in0 -> d_a, in1 -> d_b, out <- d_c.   MUX: c -> d_a, in1 -> d_b, in0 -> d_c, out <- d_a (as mux_host_one)
-        HIPCHECK(ctx, hipMemcpyPeerAsync(peer->d_a, peer->device, at(mux ? d_c : d_in0, b), ctx->device, bytes, peer->stream));
-        if (d_in1) HIPCHECK(ctx, hipMemcpyPeerAsync(peer->d_b, peer->device, at(d_in1, b), ctx->device, bytes, peer->stream));
-        if (mux) HIPCHECK(ctx, hipMemcpyPeerAsync(peer->d_c, peer->device, at(d_in0, b), ctx->device, bytes, peer->stream));
-        const int rc = mux ? run(peer, peer->d_a, peer->d_c, peer->d_b, peer->d_a, cnt, peer->stream)
-                           : run(peer, nullptr, peer->d_a, d_in1 ? peer->d_b : nullptr, peer->d_c, cnt, peer->stream);
-        if (rc) return fail(ctx, rc, peer->err);
-        HIPCHECK(ctx, hipMemcpyPeerAsync((uint32_t*)d_out + b * w, ctx->device, mux ? peer->d_a : peer->d_c, peer->device, bytes, peer->stream));
-        HIPCHECK(ctx, hipEventRecord(peer->ev_shard, peer->stream));
+        ok = ok && hip(pull(peer, peer->d_a, at(mux ? d_c : d_in0, b), bytes), "copy of the first operand to the peer");
+        if (ok && d_in1) ok = hip(pull(peer, peer->d_b, at(d_in1, b), bytes), "copy of the second operand to the peer");
+        if (ok && mux) ok = hip(pull(peer, peer->d_c, at(d_in0, b), bytes), "copy of the third operand to the peer");
+        ok = ok && hip(hipEventRecord(peer->ev_sh[1], peer->stream), "hipEventRecord");
+        if (ok) {
+            const int rc = mux ? run(peer, peer->d_a, peer->d_c, peer->d_b, peer->d_a, cnt, peer->stream)
+                               : run(peer, nullptr, peer->d_a, d_in1 ? peer->d_b : nullptr, peer->d_c, cnt, peer->stream);
+            if (rc) { first_rc = rc; first_err = "device " + std::to_string(peer->device) + ": " + peer->err; ok = false; }
+        }
+        ok = ok && hip(hipEventRecord(peer->ev_sh[2], peer->stream), "hipEventRecord");
+        if (ok) {
+            void* dst = (uint32_t*)d_out + b * w;
+            const void* src = mux ? peer->d_a : peer->d_c;
+            ok = hip(peer_copies ? hipMemcpyPeerAsync(dst, ctx->device, src, peer->device, bytes, peer->stream) : hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, peer->stream),
+                     "copy of the outputs to the primary");
+        }
+        // whatever was enqueued on the peer's stream so far is fenced by this event, complete or not
+        if (hipEventRecord(peer->ev_shard, peer->stream) == hipSuccess) { launched.push_back(peer); peer->shard_timed = ok; }
+        else (void)hipGetLastError();
     }
-    if (int rc = use(ctx)) return rc;
-    for (int d = 1; d < n_dev; d++)
-        if (shard_begin(count, d + 1, n_dev) > shard_begin(count, d, n_dev)) HIPCHECK(ctx, hipStreamWaitEvent(s, ctx->peers[d - 1]->ev_shard, 0));
+    (void)hipSetDevice(ctx->device);
+    for (rtfhe_ctx* peer : launched)
+        if (hipStreamWaitEvent(s, peer->ev_shard, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            // last resort: the caller must not see d_out before the peer is done with it
+            (void)hipSetDevice(peer->device); (void)hipStreamSynchronize(peer->stream); (void)hipSetDevice(ctx->device);
+        }
+    if (first_rc) return fail(ctx, first_rc, first_err);
     return 0;
 }
 

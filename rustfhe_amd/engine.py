@@ -180,10 +180,18 @@ class Engine:
         self._ck(self.L.rtfhe_bootstrap_batch_dev(self.h, self._dev(d_tlwe), self._dev(d_out), count, C.c_void_p(stream) if stream else None))
 
     def memory_bytes(self, d=0):
-        """Device memory entry d of the context holds right now (keys in every layout built so far, tables, staging, scratch)."""
+        """Device memory entry d of the context holds right now: keys in every form built so far, staging and scratch (not the twiddle tables, not
+        live circuits' sample buffers)."""
         b = C.c_size_t()
         self._ck(self.L.rtfhe_ctx_memory_bytes(self.h, d, C.byref(b)))
         return b.value
+
+    def peer_info(self, d):
+        """What the runtime reported about entry d >= 1 of a multi-device context against the primary (peer access both ways, whether enabling it
+        worked, link type and hops) and the phases of that entry's share of the last device-resident sharded batch; a dict (rtfhe_peer_info)."""
+        info = _ffi.PeerInfo()
+        self._ck(self.L.rtfhe_ctx_peer_info(self.h, d, C.byref(info)))
+        return info.as_dict()
 
     def circuit_wave_dev(self, d_ops, d_idx0, d_idx1, d_idx_out, d_wires, num_wires, count, stream=None):
         """One dependency wave of a netlist; wire indices / opcodes are validated on the device against num_wires
@@ -340,6 +348,16 @@ class FftPlan:
     def set_twiddles(self, ifft_table, fft_table):
         a, b = _np(ifft_table, np.float64).reshape(2 * self.N), _np(fft_table, np.float64).reshape(2 * self.N)
         self._ck(self.L.rtfhe_fft_plan_set_twiddles(self.h, _ptr(a), _ptr(b)))
+
+
+def device_link(dev_a, dev_b):
+    """What the runtime reports between two devices of the node (rtfhe_device_link): {"can_access", "link", "link_type", "hops"}."""
+    L = _ffi.load()
+    can, lt, hops = C.c_int32(), C.c_uint32(), C.c_uint32()
+    rc = L.rtfhe_device_link(dev_a, dev_b, C.byref(can), C.byref(lt), C.byref(hops))
+    if rc != 0:
+        raise RtfheError(rc, (L.rtfhe_last_error(None) or b"").decode())
+    return {"can_access": can.value, "link_type": lt.value, "link": _ffi.PeerInfo.LINK_NAMES.get(lt.value, "type %d" % lt.value), "hops": hops.value}
 
 
 def pinned_empty(shape, dtype=np.uint32):

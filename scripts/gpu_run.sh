@@ -11,7 +11,7 @@
 #   ntt              bench.py --backend ntt-exact
 #   sweep[:N[:backend]]   scripts/sweep.py over the usual batch sizes (N = 1024 default, 2048; backend fft|ntt|xfft)
 #   circuit          scripts/bench_circuit.py (the adder netlists)
-#   profile          rocprofv3 kernel trace + PMC passes of the headline (scripts/profile_gpu.sh r05)
+#   profile          rocprofv3 kernel trace + PMC passes of the headline on the driver's flags, --steps 20 --warmup 5 (scripts/profile_gpu.sh r06)
 #   profile2048      counters of the N = 2048 kernel (scripts/profile_n2048.sh eo)
 #   pmc:<kernel>:<gates>[:N[:matrix|plain[:fft|ntt]]]   counters of one kernel family on a batch (scripts/profile_kernel.sh)
 #   ab:<N>:<gates>:<rounds>:<lib>[,<lib>...]   same-process A/B of builds under build/ab/ ("shipped" = rustfhe_amd/librtfhe_hip.so)
@@ -23,6 +23,7 @@
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
+export RTFHE_BENCH_STRICT=1     # bench.py: a measuring process that dies in a side leg is exit code 86 here, not 0 (the line is printed either way)
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 # A step that was KILLED (timeout, signal) stops the run: no GPU step is started behind a dead one.  A step that merely failed (a red test, a
@@ -44,7 +45,7 @@ for step in "$@"; do
     sweep)   n=${a1:-1024}; be=${a2:-fft}; sizes=1,256,512,768,1024,1280,1536,2048,4096,8192; [ $n = 2048 ] && sizes=1,256,512,768,1024,2048; [ $be = ntt ] && sizes=1,512,1024; [ $be = xfft ] && sizes=1,256,512,768,1024,2048,4096
              run sweep env RTFHE_N=$n RTFHE_BACKEND=$be RTFHE_SKIP_STAGES=1 bash -c "timeout -k 10 300 python scripts/sweep.py $sizes > $O/sweep_N${n}_$be.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/sweep_N${n}_$be.log; exit \$rc" ;;
     circuit) run circuit bash -c "timeout -k 10 300 python scripts/bench_circuit.py > $O/bench_circuit.log 2>&1; rc=\$?; grep -v amdgpu.ids $O/bench_circuit.log | tail -12; exit \$rc" ;;
-    profile) run profile bash -c "bash scripts/profile_gpu.sh r05 > $O/profile.log 2>&1; rc=\$?; tail -3 $O/profile.log; cp -r gpurun_out/profiles_r05 $O/ 2>/dev/null; exit \$rc" ;;
+    profile) run profile bash -c "bash scripts/profile_gpu.sh r06 > $O/profile.log 2>&1; rc=\$?; tail -3 $O/profile.log; cp -r gpurun_out/profiles_r06 $O/ 2>/dev/null; exit \$rc" ;;
     profile2048) run profile2048 bash -c "bash scripts/profile_n2048.sh ${a1:-eo} > $O/profile_n2048.log 2>&1; rc=\$?; tail -3 $O/profile_n2048.log; cp gpurun_out/profiles_n2048/pmc_n2048_${a1:-eo}.json $O/ 2>/dev/null; exit \$rc" ;;
     pmc)     run "pmc $a1" env RTFHE_BACKEND=${a5:-fft} bash -c "bash scripts/profile_kernel.sh $a1 $a2 ${a3:-1024} $a4 > $O/pmc_$a1.log 2>&1; rc=\$?; tail -60 $O/pmc_$a1.log; cp gpurun_out/pmc_kernel/pmc_${a1}_N${a3:-1024}_g$a2.json $O/ 2>/dev/null; exit \$rc" ;;
     ab)      libs=$(echo "$a4" | tr ',' ' ' | sed -E 's#(^| )shipped#\1rustfhe_amd/librtfhe_hip.so#g; s#(^| )([A-Za-z0-9_]+)( |$)#\1build/ab/\2.so\3#g; s#(^| )([A-Za-z0-9_]+)( |$)#\1build/ab/\2.so\3#g')

@@ -7,7 +7,11 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-secondary $@"      # default --steps/--warmup: the headline launches of the bench line only
+# the DRIVER's command (--steps 20 --warmup 5) unless the caller gives its own flags: the steady launches of this trace are the launches the
+# bench line's ms_per_step is made of (scripts/summarize_prof.py reports them apart from the clock ramp of the first launches)
+[ $# -eq 0 ] && set -- --steps 20 --warmup 5
+export RTFHE_PROF_WARMUP=$(echo "$@" | sed -n 's/.*--warmup \([0-9]*\).*/\1/p'); RTFHE_PROF_WARMUP=${RTFHE_PROF_WARMUP:-2}
+ARGS="--no-cpu-baseline --no-secondary $@"      # the headline launches of the bench line only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py $ARGS > $OUT/kt.log 2>&1 || { tail -20 $OUT/kt.log; exit 1; }
 # the same command with the secondary measurements (every BASELINE config + the NTT backend): one stats row per kernel family
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_all -- python3 $REPO/bench.py --no-cpu-baseline "$@" > $OUT/kt_all.log 2>&1 || { echo "kt_all failed"; tail -5 $OUT/kt_all.log; }

@@ -203,19 +203,28 @@ MODE
 
 
 @pytest.mark.parametrize("mode, crash", [("os.abort()", True), ("print(json.dumps({'metric': 'm', 'value': 1.0, 'cpu_baseline': {'value': 2}, 'secondary': {}}), flush=True)", False)])
-def test_supervisor_prints_the_last_complete_line_even_if_the_measuring_process_dies(tmp_path, capfd, mode, crash):
+def test_supervisor_prints_the_last_complete_line_even_if_the_measuring_process_dies(tmp_path, capfd, monkeypatch, mode, crash):
     import bench
     child = tmp_path / "inner.py"
     child.write_text(FAKE_INNER.replace("MODE", mode))
+    monkeypatch.delenv("RTFHE_BENCH_STRICT", raising=False)
     rc = bench.supervise([sys.executable, str(child)])
     out = capfd.readouterr().out.strip().split("\n")
-    assert rc == 0 and len(out) == 1, out                       # ONE line on stdout, exit code 0
+    assert rc == 0 and len(out) == 1, out                       # ONE line on stdout; without RTFHE_BENCH_STRICT the exit code stays 0
     line = json.loads(out[0])
     assert line["value"] == 1.0 and line["cpu_baseline"] == {"value": 2} and "provisional" not in line
     if crash:
+        assert line["ok"] is False                              # ... but the line itself says that the run is not whole
         assert line["side_leg_crash"]["signal"] == "SIGABRT" and line["side_leg_crash"]["legs_not_completed"] == ["secondary"]
     else:
-        assert "side_leg_crash" not in line and line["secondary"] == {}
+        assert line["ok"] is True and "side_leg_crash" not in line and line["secondary"] == {}
+    # the evidence runs (scripts/gpu_run.sh) set RTFHE_BENCH_STRICT=1: the same line, and a distinct non-zero exit code for the crash
+    monkeypatch.setenv("RTFHE_BENCH_STRICT", "1")
+    rc = bench.supervise([sys.executable, str(child)])
+    out = capfd.readouterr().out.strip().split("\n")
+    assert len(out) == 1 and json.loads(out[0])["ok"] is (not crash)
+    assert rc == (bench.SIDE_LEG_CRASH_RC if crash else 0) and bench.SIDE_LEG_CRASH_RC not in (0, 1, 2)
+    assert "RTFHE_BENCH_STRICT=1" in open(os.path.join(ROOT, "scripts", "gpu_run.sh")).read()
 
 
 def test_supervisor_without_any_line_reports_the_exit_code(tmp_path, capfd):
@@ -301,16 +310,20 @@ def test_a_wrong_gpu_output_is_reported_as_a_mismatch(baseline_inputs, monkeypat
 @pytest.mark.gpu
 @pytest.mark.parametrize("where", ["cpu_child", "secondary"])
 def test_bench_headline_survives_an_abort_in_a_side_leg(where):
-    env = dict(os.environ, RTFHE_BENCH_TEST_ABORT=where)
+    """... and says so: a CPU-baseline child that dies is an error inside its own leg of a whole line ("ok": true); the measuring process itself
+    dying in a side leg is "ok": false + side_leg_crash and, under RTFHE_BENCH_STRICT=1 (what scripts/gpu_run.sh exports), exit code 86."""
+    import bench
+    env = dict(os.environ, RTFHE_BENCH_TEST_ABORT=where, RTFHE_BENCH_STRICT="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-gates-per-thread", "1"],
                        capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == (0 if where == "cpu_child" else bench.SIDE_LEG_CRASH_RC), r.stderr[-2000:]
     lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["value"] > 0 and line["outputs_decrypt_correctly"] and line["roofline"]["frac"] > 0
     if where == "cpu_child":
-        assert "SIGABRT" in line["cpu_baseline"]["error"] and "secondary" in line
+        assert "SIGABRT" in line["cpu_baseline"]["error"] and "secondary" in line and line["ok"] is True
     else:
+        assert line["ok"] is False
         assert line["side_leg_crash"]["signal"] == "SIGABRT" and line["side_leg_crash"]["legs_not_completed"] == ["secondary"]
         assert "value" in line["cpu_baseline"] or "error" in line["cpu_baseline"]

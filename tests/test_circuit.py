@@ -243,3 +243,76 @@ def test_prefix_adder_8bit_on_gpu(engine, orc, params, keys):
     dec = np.array(keys.decrypt_bits(nn.run(graph=True).outputs().reshape(-1, params.n + 1))).reshape(reps, 9)
     assert np.array_equal((dec * (1 << np.arange(9))).sum(axis=1), A + B)
     nn.close()
+
+
+@pytest.mark.gpu
+def test_a_recorded_circuit_follows_a_key_change(params, keys):
+    """Advisor r5: a circuit's graph bakes the addresses of the key forms its kernels read.  A DIFFERENT key loaded afterwards must be what a replay
+    computes with -- every form that exists is rebuilt in place by the load -- and where that is impossible (an exact backend's form after a key
+    that has no torus form) the replay must fail instead of using the old key.  One wave of 300 gates takes the four-waves-per-gate kernel,
+    i.e. the SECOND layout of the spectra; the same wave is recorded on the split-FFT backend as well."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    e = R.Engine(p, 0)
+    try:
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        G, n1 = 300, p.n + 1
+        rng = np.random.default_rng(44)
+        b0, b1 = rng.integers(0, 2, G).astype(np.uint8), rng.integers(0, 2, G).astype(np.uint8)
+        wires = torch.zeros((3 * G, n1), dtype=torch.int32, device="cuda")
+        i32 = lambda v: torch.tensor(np.asarray(v, np.int32), dtype=torch.int32, device="cuda")
+        ops, i0, i1, io = i32([R.NAND] * G), i32(np.arange(G)), i32(G + np.arange(G)), i32(2 * G + np.arange(G))
+        offs = np.array([0, G], np.int32)
+
+        def put_inputs(key0, s0, s1):
+            wires[:G] = torch.from_numpy(R.encrypt_bits(p, key0, b0, s0).view(np.int32)).cuda()
+            wires[G:2 * G] = torch.from_numpy(R.encrypt_bits(p, key0, b1, s1).view(np.int32)).cuda()
+            wires[2 * G:] = 0
+
+        def outputs(key0):
+            return list(R.decrypt_bits(p, key0, wires[2 * G:].cpu().numpy().view(np.uint32)))
+
+        put_inputs(keys.key0, 1, 2)
+        c_mirror = e.circuit_create(ops, i0, i1, io, offs, wires, 3 * G)
+        e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        c_exact = e.circuit_create(ops, i0, i1, io, offs, wires, 3 * G)
+        e.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+        for c in (c_mirror, c_exact):
+            wires[2 * G:] = 0
+            e.circuit_launch(c); e.sync()
+            assert outputs(keys.key0) == list(1 - (b0 & b1))
+        # a different key set, loaded over the first
+        k0b, k1b, bkb, kskb = R.keygen(p, 424242)
+        assert not np.array_equal(k0b, keys.key0)
+        e.load_bk_torus(bkb)
+        e.load_ksk(kskb)
+        put_inputs(k0b, 3, 4)
+        eager = e.gate_batch(R.NAND, wires[:G].cpu().numpy().view(np.uint32), wires[G:2 * G].cpu().numpy().view(np.uint32))
+        for c in (c_mirror, c_exact):
+            wires[2 * G:] = 0
+            e.circuit_launch(c); e.sync()
+            assert outputs(k0b) == list(1 - (b0 & b1)), "the replay computed with the old key"
+        e.circuit_launch(c_mirror); e.sync()
+        assert np.array_equal(wires[2 * G:].cpu().numpy().view(np.uint32), eager)
+        # the same key as spectra: no torus form any more -- the mirror circuit follows, the exact one refuses
+        spectra = e.export_bk_fft()
+        e.load_bk_fft(spectra)
+        wires[2 * G:] = 0
+        e.circuit_launch(c_mirror); e.sync()
+        assert np.array_equal(wires[2 * G:].cpu().numpy().view(np.uint32), eager)
+        with pytest.raises(R.RtfheError) as err:
+            e.circuit_launch(c_exact)
+        assert err.value.code == R._ffi.ERR_STATE
+        # a torus-form key again: a NEW exact circuit works (the old one stays refused)
+        e.load_bk_torus(bkb)
+        e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        c_exact2 = e.circuit_create(ops, i0, i1, io, offs, wires, 3 * G)
+        wires[2 * G:] = 0
+        e.circuit_launch(c_exact2); e.sync()
+        assert outputs(k0b) == list(1 - (b0 & b1))
+        for c in (c_mirror, c_exact, c_exact2):
+            e.circuit_destroy(c)
+    finally:
+        e.close()

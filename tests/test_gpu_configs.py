@@ -600,3 +600,54 @@ def test_second_key_layouts_are_built_by_the_first_batch_that_reads_them(params,
         assert keys.decrypt_bits(first.cpu().numpy().view(np.uint32)) == list(1 - (b0[:300] & b1[:300]))
     finally:
         e.close()
+
+
+def test_mux_batches_on_two_streams_and_inside_a_capture(params, keys):
+    """Advisor r5: the MUX intermediates belong to the stream the batch runs on.  Two MUX batches enqueued on two streams without a host
+    synchronisation between them give the single-stream words; inside a caller's capture the call is refused until the stream's buffers exist
+    (nothing may be allocated there), then captured, and the captured buffers survive a later, larger eager batch on the same stream."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    e = R.Engine(p, 0)
+    try:
+        e.load_bk_torus(keys.bk_t)
+        e.load_ksk(keys.ksk)
+        k = 700
+        rng = np.random.default_rng(321)
+        bits = rng.integers(0, 2, (6, k))
+        d = [torch.from_numpy(keys.encrypt_bits(b).view(np.int32)).cuda() for b in bits]
+        ref_a, ref_b = torch.empty_like(d[0]), torch.empty_like(d[0])
+        e.mux_batch_dev(d[0], d[1], d[2], ref_a, k); e.sync()
+        e.mux_batch_dev(d[3], d[4], d[5], ref_b, k); e.sync()
+        assert keys.decrypt_bits(ref_a.cpu().numpy().view(np.uint32)) == list(np.where(bits[0], bits[2], bits[1]))
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        out_a, out_b = torch.zeros_like(d[0]), torch.zeros_like(d[0])
+        for _ in range(3):                                   # overlapping launches: the streams run side by side on the card
+            e.mux_batch_dev(d[0], d[1], d[2], out_a, k, s1.cuda_stream)
+            e.mux_batch_dev(d[3], d[4], d[5], out_b, k, s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
+        # capture: refused on a stream that has no buffers yet, accepted once it has
+        s3 = torch.cuda.Stream()
+        cap_out = torch.zeros_like(d[0])
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(R.RtfheError) as err:
+            with torch.cuda.graph(g, stream=s3):
+                e.mux_batch_dev(d[0], d[1], d[2], cap_out, 16, torch.cuda.current_stream().cuda_stream)
+        assert err.value.code == R._ffi.ERR_STATE
+        torch.cuda.synchronize()
+        e.mux_batch_dev(d[0], d[1], d[2], cap_out, 16, s3.cuda_stream); torch.cuda.synchronize()      # eager, sizes this stream's buffers
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s3):
+            e.mux_batch_dev(d[0], d[1], d[2], cap_out, 16, torch.cuda.current_stream().cuda_stream)
+        cap_out.zero_(); g.replay(); torch.cuda.synchronize()
+        assert torch.equal(cap_out[:16], ref_a[:16])
+        before = e.memory_bytes()
+        e.mux_batch_dev(d[0], d[1], d[2], out_a, k, s3.cuda_stream); torch.cuda.synchronize()          # larger: new buffers, the captured ones stay
+        assert torch.equal(out_a, ref_a) and e.memory_bytes() > before
+        cap_out.zero_(); g.replay(); torch.cuda.synchronize()
+        assert torch.equal(cap_out[:16], ref_a[:16])
+    finally:
+        e.close()

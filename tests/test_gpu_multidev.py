@@ -142,6 +142,98 @@ def test_a_batch_resident_on_the_primary_is_sharded_behind_the_c_abi(params, key
         m.close(); s.close()
 
 
+def test_peer_info_says_what_the_runtime_reported(params, keys):
+    """rtfhe_ctx_peer_info: every entry after the primary reports whether it names the primary's own device, the peer-access
+    answers in both directions, whether enabling it worked, the link the runtime reports, and -- after a device-resident sharded batch has
+    completed -- the three phases of its share (pull, bootstrap, push) from events on its own stream.  On this one-GPU box every entry names
+    device 0: same_device, nothing to enable, no link; the phases are real."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0, 0, 0])
+    try:
+        for d in (1, 2):
+            i = m.peer_info(d)
+            assert i["device"] == 0 and i["same_device"] == 1
+            assert (i["can_access_from_primary"], i["can_access_to_primary"], i["enabled_from_primary"], i["enabled_to_primary"]) == (0, 0, 0, 0)
+            assert i["link"] == "not reported" and i["scatter_ms"] is None and i["compute_ms"] is None and i["gather_ms"] is None
+        for d in (0, 3, -1):
+            with pytest.raises(R.RtfheError):
+                m.peer_info(d)
+        with pytest.raises(R.RtfheError):
+            s.peer_info(1)                                 # a single-device context has no entry 1
+        G = 2 * 8192
+        rng = np.random.default_rng(9)
+        b0, b1 = rng.integers(0, 2, 512), rng.integers(0, 2, 512)
+        d0 = torch.from_numpy(np.tile(keys.encrypt_bits(b0), (G // 512, 1)).view(np.int32)).cuda()
+        d1 = torch.from_numpy(np.tile(keys.encrypt_bits(b1), (G // 512, 1)).view(np.int32)).cuda()
+        out, ref = torch.empty_like(d0), torch.empty_like(d0)
+        st = torch.cuda.current_stream().cuda_stream
+        m.gate_batch_dev(R.NAND, d0, d1, out, G, st); m.sync(st)
+        s.gate_batch_dev(R.NAND, d0, d1, ref, G, st); s.sync(st)
+        assert torch.equal(out, ref)
+        lo, hi = R.shard_range(G, 1, 3)
+        assert (lo, hi) == (G // 3, 2 * G // 3)            # [count d / D, count (d + 1) / D)
+        for d in (1, 2):
+            i = m.peer_info(d)
+            assert i["scatter_ms"] is not None and i["scatter_ms"] >= 0 and i["gather_ms"] >= 0
+            assert i["compute_ms"] > 1.0, i                # ~ 5,461 gates: tens of milliseconds
+        # a batch that gives the last entry no gate leaves its phases unreported
+        m.gate_batch_dev(R.NAND, d0, d1, out, 2, st); m.sync(st)
+        assert m.peer_info(2)["compute_ms"] is None and m.peer_info(1)["compute_ms"] is not None
+    finally:
+        m.close(); s.close()
+
+
+def test_batch_pointers_that_are_not_the_primarys_device_memory_take_the_default_copy(params, keys):
+    """gpu_accessible admits pinned-host buffers as *_dev arguments; on a multi-device context the shards of such a batch may not be handed to
+    hipMemcpyPeerAsync as memory of the primary (advisor r5): they are copied with hipMemcpyDefault and the results are the same words."""
+    import ctypes as C
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0, 0])
+    try:
+        k, w = 600, p.n + 1
+        rng = np.random.default_rng(10)
+        b0, b1 = rng.integers(0, 2, k), rng.integers(0, 2, k)
+        c0, c1 = keys.encrypt_bits(b0), keys.encrypt_bits(b1)
+        h0, h1, ho = R.pinned_empty((k, w)), R.pinned_empty((k, w)), R.pinned_empty((k, w))
+        h0[:], h1[:], ho[:] = c0, c1, 0
+        ptr = lambda a: C.c_void_p(a.ctypes.data)
+        assert m.L.rtfhe_gate_batch_dev(m.h, R.NAND, ptr(h0), ptr(h1), ptr(ho), k, None) == 0
+        m.sync()
+        assert np.array_equal(np.asarray(ho), s.gate_batch(R.NAND, c0, c1))
+        assert keys.decrypt_bits(np.asarray(ho)) == list(1 - (b0 & b1))
+    finally:
+        m.close(); s.close()
+
+
+def test_the_split_fft_backend_on_every_entry(params, keys):
+    """RTFHE_BACKEND_FFT_SPLIT_EXACT on a multi-device context: the split key spectra are derived per entry from the replicated torus key; a
+    sharded device-resident batch equals the single-device one and the NTT backend's, word for word."""
+    import torch
+    import rustfhe_amd as R
+    p = R.Params()
+    m, s = _pair(R, p, keys.bk_t, keys.ksk, [0, 0])
+    try:
+        k = 1500
+        rng = np.random.default_rng(12)
+        b0, b1 = rng.integers(0, 2, k), rng.integers(0, 2, k)
+        d0 = torch.from_numpy(keys.encrypt_bits(b0).view(np.int32)).cuda()
+        d1 = torch.from_numpy(keys.encrypt_bits(b1).view(np.int32)).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        a, b, c = torch.empty_like(d0), torch.empty_like(d0), torch.empty_like(d0)
+        s.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        s.gate_batch_dev(R.NAND, d0, d1, c, k, st); s.sync(st)
+        m.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT); s.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        s.gate_batch_dev(R.NAND, d0, d1, a, k, st); m.gate_batch_dev(R.NAND, d0, d1, b, k, st); m.sync(st); s.sync(st)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        assert keys.decrypt_bits(a.cpu().numpy().view(np.uint32)) == list(1 - (b0 & b1))
+    finally:
+        m.close(); s.close()
+
+
 def test_a_device_resident_batch_inside_a_callers_capture_stays_on_the_primary(params, keys):
     """Inside a stream capture the staging buffers of the other entries are not the capture's to bake in: the whole batch runs on the primary
     (fused kernel, canonical key layout), and the captured graph replays to the same words."""
