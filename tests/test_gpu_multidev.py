@@ -178,9 +178,10 @@ def test_peer_info_says_what_the_runtime_reported(params, keys):
             i = m.peer_info(d)
             assert i["scatter_ms"] is not None and i["scatter_ms"] >= 0 and i["gather_ms"] >= 0
             assert i["compute_ms"] > 1.0, i                # ~ 5,461 gates: tens of milliseconds
-        # a batch that gives the last entry no gate leaves its phases unreported
-        m.gate_batch_dev(R.NAND, d0, d1, out, 2, st); m.sync(st)
-        assert m.peer_info(2)["compute_ms"] is None and m.peer_info(1)["compute_ms"] is not None
+        # a batch that gives an entry no gate leaves its phases unreported: one gate over three entries is [0, 0), [0, 0), [0, 1)
+        assert [R.shard_range(1, d, 3) for d in range(3)] == [(0, 0), (0, 0), (0, 1)]
+        m.gate_batch_dev(R.NAND, d0, d1, out, 1, st); m.sync(st)
+        assert m.peer_info(1)["compute_ms"] is None and m.peer_info(2)["compute_ms"] is not None
     finally:
         m.close(); s.close()
 

@@ -7,7 +7,11 @@ key0[i] = 1 and TRGSW(0) where key0[i] = 0 -- the two operands the reference's t
   trgsw_cmux  (:395-426):  TRGSW(i).cmux(rep_1, rep_0) = cross(rep_1 - rep_0) + rep_0 decrypts to pol_i (all-One / all-Zero polynomials).
 TRLWE encryption and decryption are done here in numpy from their definitions (trlwe.rs:127-147: b = a (*) s + m + e, phase = b - a (*) s, noise
 2^-25), so nothing of the oracle's external product, decomposition or transform is involved: a wrong gadget, a swapped component or a wrong
-sign in the device's product fails these tests whatever the oracle restates.  Every backend, N = 1024 and N = 2048."""
+sign in the device's product fails these tests whatever the oracle restates.  Every backend, N = 1024 and N = 2048.
+
+Tolerance: the reference states 2e-3 at its N = 1024.  What the bound covers is the gadget decomposition's rounding error (18 of 32 bits kept, with
+the biased offset of make_decomp_mask) summed over the ~N/2 set bits of the key: it is a systematic ~1e-3 at N = 1024 and ~2e-3 at
+N = 2048 (measured: 0.0017-0.0023 at every coefficient), so the bound scales with N here: 2e-3 * N / 1024."""
 import numpy as np
 import pytest
 
@@ -49,6 +53,7 @@ def test_trgsw_cross_and_cmux_mean_what_the_reference_says(N, n, backends):
     ones, zeros = np.flatnonzero(key0 == 1), np.flatnonzero(key0 == 0)
     assert ones.size >= 3 and zeros.size >= 3
     rng = np.random.default_rng(N)
+    tol = 2e-3 * N / 1024
     eng = R.Engine(p, 0)
     try:
         eng.load_bk_torus(bk)
@@ -67,7 +72,7 @@ def test_trgsw_cross_and_cmux_mean_what_the_reference_says(N, n, backends):
             for k, i in enumerate(idx):
                 want = m if key0[i] else np.zeros(N, np.uint32)
                 dist = torus_distance(trlwe_phase(key1, out[k]), want)
-                assert dist.max() < 2e-3, (name, N, int(i), int(key0[i]), float(dist.max()))
+                assert dist.max() < tol, (name, N, int(i), int(key0[i]), float(dist.max()))
             # --- cmux: TRGSW(i).cmux(rep_1, rep_0) = cross(rep_1 - rep_0) + rep_0 decrypts to pol_i
             rep_1 = np.stack([trlwe_encrypt(rng, key1, one_pol) for _ in idx])
             rep_0 = np.stack([trlwe_encrypt(rng, key1, zero_pol) for _ in idx])
@@ -78,6 +83,6 @@ def test_trgsw_cross_and_cmux_mean_what_the_reference_says(N, n, backends):
                 bits = (ph < 0x80000000).astype(np.uint8)                          # torus_pol2binary_pol: f < 0.5 -> One (trlwe.rs:89-99)
                 assert np.all(bits == key0[i]), (name, N, int(i), int(key0[i]), int((bits != key0[i]).sum()))
                 want = one_pol if key0[i] else zero_pol
-                assert torus_distance(ph, want).max() < 2e-3
+                assert torus_distance(ph, want).max() < tol
     finally:
         eng.close()
