@@ -362,7 +362,6 @@ int rtfhe_set_backend(rtfhe_ctx* ctx, int backend) {
     if (int rc = use(ctx)) return rc;
     if (backend != RTFHE_BACKEND_FFT64_MIRROR && backend != RTFHE_BACKEND_NTT_EXACT && backend != RTFHE_BACKEND_FFT_SPLIT_EXACT)
         return fail(ctx, RTFHE_ERR_INVALID, "unknown backend");
-    if (backend == RTFHE_BACKEND_FFT_SPLIT_EXACT && ctx->logn != 10) return fail(ctx, RTFHE_ERR_INVALID, "the split-FFT exact backend is built for N = 1024");
     ctx->backend = backend;
     for (rtfhe_ctx* peer : ctx->peers) peer->backend = backend;
     return 0;

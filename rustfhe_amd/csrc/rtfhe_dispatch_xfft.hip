@@ -1,9 +1,11 @@
-// rtfhe_dispatch_xfft.hip -- the split-FFT exact backend (rtfhe_xfft.hpp, N = 1024): host tables, the split key spectra, kernel shapes per batch.
+// rtfhe_dispatch_xfft.hip -- the split-FFT exact backend (rtfhe_xfft.hpp; N = 1024: rtfhe_kernels_xfft.hpp, N = 2048: rtfhe_kernels_xfft2.hpp): host
+// tables, the split key spectra, kernel shapes per batch.
 #include "rtfhe_host.hpp"
 
 #include <cmath>
 
 #include "rtfhe_kernels_xfft.hpp"
+#include "rtfhe_kernels_xfft2.hpp"
 
 using namespace rtfhe;
 using namespace rtfhe_host;
@@ -19,11 +21,14 @@ cplx unit(long double angle) { return make_double2((double)cosl(angle), (double)
 //   forward, stage s (1..9), block B:  w = exp(i theta_{s,B} / 2),  theta_{1,0} = pi/2,  theta_{s+1,2B} = theta_{s,B}/2,  theta_{s+1,2B+1} = theta_{s,B}/2 + pi
 //   inverse, stage t (1..9), q < 2^(t-1):  w = exp(-2 pi i q / 2^t)
 //   untwist, j < 512:  exp(-i (pi/2) j / 512) / 512
-std::vector<cplx> xfft_device_table() {
-    const long double PI = 3.141592653589793238462643383279502884L;
+const long double PI = 3.141592653589793238462643383279502884L;
+
+// root_theta: the ring of the 512-point forward transform is C[X]/(X^512 - exp(i root_theta)): pi/2 at N = 1024; at N = 2048 the two halves of the
+// 1024-point transform are such rings with pi/4 and pi/4 + pi (rtfhe_kernels_xfft2.hpp)
+std::vector<cplx> xfft_device_table(long double root_theta = PI / 2) {
     constexpr int n = 512, LOG = 9;
     std::vector<std::vector<long double>> theta(LOG + 2);
-    theta[1] = {PI / 2};
+    theta[1] = {root_theta};
     for (int s = 1; s <= LOG; s++) {
         theta[s + 1].resize(theta[s].size() * 2);
         for (size_t B = 0; B < theta[s].size(); B++) { theta[s + 1][2 * B] = theta[s][B] / 2; theta[s + 1][2 * B + 1] = theta[s][B] / 2 + PI; }
@@ -59,6 +64,32 @@ std::vector<cplx> xfft_device_table() {
     return tb;
 }
 
+// N = 2048 (XTw2): the forward tables of the two halves, the inverse tables (the standard DIT twiddles, as at N = 1024) and the last inverse
+// stage's U_q = psi^-q / n, V_q = omega^-q U_q (psi = exp(i (pi/2) / n), omega = exp(2 pi i / n), n = 1024), cut by the half that uses them:
+// half h reads q = lane + 64 (4 h + k), k < 4
+std::vector<cplx> xfft2_device_table() {
+    typedef xfft::XTw2 T2;
+    std::vector<cplx> tb(T2::TOTAL, make_double2(0.0, 0.0));
+    const std::vector<cplx> inv = xfft_device_table();
+    for (int h = 0; h < 2; h++) {
+        const std::vector<cplx> half = xfft_device_table(PI / 4 + (long double)h * PI);
+        for (int e = 0; e < T2::FH; e++) tb[T2::F + h * T2::FH + e] = half[XTw::F1 + e];
+    }
+    for (int e = 0; e < 7 * 8; e++) tb[T2::I2 + e] = inv[XTw::I2 + e];
+    for (int e = 0; e < 7 * 64; e++) tb[T2::I3 + e] = inv[XTw::I3 + e];
+    constexpr int n = 1024;
+    for (int h = 0; h < 2; h++)
+        for (int k = 0; k < 4; k++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int q = lane + 64 * (4 * h + k);
+                const long double ua = -(PI / 2) * (long double)q / (long double)n, va = ua - 2 * PI * (long double)q / (long double)n;
+                const cplx u = unit(ua), v = unit(va);
+                tb[T2::UV + ((h * 2 + 0) * 4 + k) * 64 + lane] = make_double2(u.x / n, u.y / n);
+                tb[T2::UV + ((h * 2 + 1) * 4 + k) * 64 + lane] = make_double2(v.x / n, v.y / n);
+            }
+    return tb;
+}
+
 template <int GATES>
 int launch_xpair_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     auto k = k_bootstrap_xpair<3, 6, 8, 2, KSQ, GATES>;
@@ -72,6 +103,31 @@ int launch_xpair_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
 }
 
 // whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU (as the other two-waves-per-gate kernels)
+template <int GATES>
+int launch_xquad_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_xquad<3, 6, 8, 2, KSQ, GATES>;
+    const size_t lds = XQuadLds::bytes(GATES, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    XBootstrapArgs a{b, ctx->d_xtw, ctx->d_xbk};
+    hipLaunchKernelGGL(k, dim3((b.count + GATES - 1) / GATES), dim3(256 * GATES), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
+// N = 2048: whole rounds of 2 gates per CU (four waves per gate: two waves per SIMD); a remainder of at most one gate per CU runs one gate per workgroup
+int launch_xquad(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_xquad);
+    const size_t out_words = mode_out_words(a, 2048);
+    const size_t cus = (size_t)ctx->num_cus, round = 2 * cus, count = (size_t)a.count;
+    const size_t full = count / round * round, rem = count - full;
+    if (full)
+        if (int rc = launch_xquad_g<2>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
+    if (!rem) return 0;
+    const BootstrapArgs tail = batch_segment(ctx, a, full, rem, out_words);
+    return rem <= cus ? launch_xquad_g<1>(ctx, tail, s) : launch_xquad_g<2>(ctx, tail, s);
+}
+
 int launch_xpair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_xpair);
     const size_t out_words = mode_out_words(a, 1024);
@@ -93,31 +149,40 @@ namespace rtfhe_host {
 
 int xfft_prepare(rtfhe_ctx* ctx) {
     if (ctx->xfft_ready) return 0;
-    if (ctx->logn != 10) return fail(ctx, RTFHE_ERR_INVALID, "the split-FFT exact backend is built for N = 1024");
     if (!ctx->d_bk_torus) return fail(ctx, RTFHE_ERR_STATE, "the split-FFT exact backend needs the bootstrapping key in torus form (rtfhe_load_bk_torus)");
+    const bool big = ctx->logn == 11;
     if (!ctx->d_xtw) {
-        const std::vector<cplx> t = xfft_device_table();
+        const std::vector<cplx> t = big ? xfft2_device_table() : xfft_device_table();
         HIPCHECK(ctx, hipMalloc((void**)&ctx->d_xtw, t.size() * sizeof(cplx)));
         HIPCHECK(ctx, hipMemcpy(ctx->d_xtw, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice));
     }
     const size_t polys = bk_word_count(ctx->p) / ctx->p.N;
     if (!ctx->d_xbk) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_xbk, 2 * bk_cplx_count(ctx->p) * sizeof(cplx)));
     constexpr int W = 4;
-    int grid = (int)((polys + W - 1) / W); if (grid > 2048) grid = 2048;
     XBkArgs a{ctx->d_xtw, ctx->d_bk_torus, ctx->d_xbk, (int32_t)polys, 2 * ctx->p.l};
-    const size_t lds = (size_t)XTw::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);
-    if (int rc = allow_lds(ctx, k_xbk_build<W>, lds)) return rc;
-    hipLaunchKernelGGL(k_xbk_build<W>, dim3(grid), dim3(64 * W), lds, ctx->stream, a);
+    if (big) {      // a work item = (polynomial, half of its spectrum)
+        int grid = (int)((2 * polys + W - 1) / W); if (grid > 2048) grid = 2048;
+        const size_t lds = (size_t)xfft::XTw2::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);
+        if (int rc = allow_lds(ctx, k_xbk_build2<W>, lds)) return rc;
+        hipLaunchKernelGGL(k_xbk_build2<W>, dim3(grid), dim3(64 * W), lds, ctx->stream, a);
+    } else {
+        int grid = (int)((polys + W - 1) / W); if (grid > 2048) grid = 2048;
+        const size_t lds = (size_t)XTw::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);
+        if (int rc = allow_lds(ctx, k_xbk_build<W>, lds)) return rc;
+        hipLaunchKernelGGL(k_xbk_build<W>, dim3(grid), dim3(64 * W), lds, ctx->stream, a);
+    }
     HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->xfft_ready = true;
     return 0;
 }
 
-int launch_bootstrap_xfft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return launch_xpair(ctx, a, s); }
+int launch_bootstrap_xfft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return ctx->logn == 11 ? launch_xquad(ctx, a, s) : launch_xpair(ctx, a, s); }
 
 // external product of `count` TRLWE samples with bk[idx[g]] on this backend (stage-level entry point)
 int launch_extprod_xfft(rtfhe_ctx* ctx, const int32_t* d_idx, const uint32_t* d_in, uint32_t* d_out, int32_t count, hipStream_t s) {
+    if (ctx->logn != 10) return fail(ctx, RTFHE_ERR_INVALID, "the stage-level external product of the split-FFT exact backend is built for N = 1024 (at N = 2048 use "
+                                                             "rtfhe_blind_rotate_batch with a step count, or the NTT backend's stage call: the products are the same words)");
     constexpr int W = 2;
     XExtProdArgs a{ctx->d_xtw, ctx->d_xbk, d_idx, d_in, d_out, count};
     const size_t lds = (size_t)XTw::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);
@@ -128,8 +193,12 @@ int launch_extprod_xfft(rtfhe_ctx* ctx, const int32_t* d_idx, const uint32_t* d_
 }
 
 int prime_xfft_kernels(rtfhe_ctx* ctx) {
-    if (ctx->logn != 10) return 0;
     const int npad = (ctx->p.n + 1 + 63) / 64 * 64;
+    if (ctx->logn == 11) {
+        if (int rc = allow_lds(ctx, k_bootstrap_xquad<3, 6, 8, 2, KSQ, 2>, XQuadLds::bytes(2, npad))) return rc;
+        if (int rc = allow_lds(ctx, k_bootstrap_xquad<3, 6, 8, 2, KSQ, 1>, XQuadLds::bytes(1, npad))) return rc;
+        return 0;
+    }
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 4>, XPairLds::bytes(4, npad))) return rc;
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 3>, XPairLds::bytes(3, npad))) return rc;
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 2>, XPairLds::bytes(2, npad))) return rc;

@@ -193,9 +193,11 @@ __device__ __forceinline__ void mac_half(double (&sre)[R], double (&sim)[R], con
 // come as w1 (registers / scalars of the caller).  A row's exchange reads are issued between the stages of the NEXT row's pass (as
 // fft_forward_multi_a's interleaved form, rtfhe_device.hpp).
 struct NoPoint { __device__ __forceinline__ void operator()(int) const {} };
+// (forward_multi_t: the pass-2 / pass-3 tables given explicitly -- [7][8] by lane >> 3 and [7][64] by lane; the N = 2048 kernel runs this
+// 512-point transform with one of two table sets, rtfhe_kernels_xfft2.hpp)
 template <int NR, typename HOOK = NoPoint>
-__device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ tw, const cplx (&w1)[7],
-                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
+__device__ __forceinline__ void forward_multi_t(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ f2, const cplx* __restrict__ f3,
+                                                const cplx (&w1)[7], double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
     typedef XAffine<10, 1, 2> X1;
     typedef XAffine<10, 2, 3> X2;
     auto pass = [&](int j, const cplx* w, auto&& between0, auto&& between1) {
@@ -211,11 +213,11 @@ __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[
         fwd_pass(re[0], im[0], w1);
         exchange<10, 1, 2, 1>(re[0], im[0], xbuf, lane, xim);
         Tw<7> w2;
-        w2.load(tw + XTw::F2 + (lane >> 3), 8);
+        w2.load(f2 + (lane >> 3), 8);
         fwd_pass(re[0], im[0], w2.w);
         exchange<10, 2, 3, 1>(re[0], im[0], xbuf, lane, xim);
         Tw<7> w3;
-        w3.load(tw + XTw::F3 + lane, 64);
+        w3.load(f3 + lane, 64);
         fwd_pass(re[0], im[0], w3.w);
         return;
     }
@@ -228,7 +230,7 @@ __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[
     }
     point(1);
     Tw<7> w2;
-    w2.load(tw + XTw::F2 + (lane >> 3), 8);
+    w2.load(f2 + (lane >> 3), 8);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         if (j == 0) pass(0, w2.w, [&] { X1::template read_half<0>(re[NR - 1], im[NR - 1], xbuf, xim, lane); }, [&] { X1::template read_half<1>(re[NR - 1], im[NR - 1], xbuf, xim, lane); wave_lds_sync(); });
@@ -238,19 +240,25 @@ __device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[
     }
     point(2);
     Tw<7> w3;
-    w3.load(tw + XTw::F3 + lane, 64);
+    w3.load(f3 + lane, 64);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         if (j == 0) pass(0, w3.w, [&] { X2::template read_half<0>(re[NR - 1], im[NR - 1], xbuf, xim, lane); }, [&] { X2::template read_half<1>(re[NR - 1], im[NR - 1], xbuf, xim, lane); wave_lds_sync(); });
         else pass(j, w3.w, nothing, nothing);
     }
 }
+template <int NR, typename HOOK = NoPoint>
+__device__ __forceinline__ void forward_multi(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ tw, const cplx (&w1)[7],
+                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
+    forward_multi_t<NR>(re, im, tw + XTw::F2, tw + XTw::F3, w1, xbuf, xim, lane, point);
+}
 
 // NR inverse transforms side by side.  in: layout L3 (the multiply-accumulate's sums); out: layout L1, untwisted, scaled and carrying MAGIC
 // (re[j][m] <-> coefficient lane + 64 m, im[j][m] <-> coefficient lane + 64 m + N/2; read with rounded_u32 / rounded_hi16).
+// (inverse_core: the nine stages alone, out: layout L1, NOT untwisted; pass-2 / pass-3 tables given explicitly -- [7][8] by lane & 7, [7][64] by lane)
 template <int NR, typename HOOK = NoPoint>
-__device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ tw,
-                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
+__device__ __forceinline__ void inverse_core(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ i2, const cplx* __restrict__ i3,
+                                             double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
     typedef XAffine<10, 3, 2> X1;
     typedef XAffine<10, 2, 1> X2;
 #pragma unroll
@@ -262,7 +270,7 @@ __device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[
     }
     point(1);
     Tw<7> w2;
-    w2.load(tw + XTw::I2 + (lane & 7), 8);
+    w2.load(i2 + (lane & 7), 8);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         if (j == 0) { X1::template read_half<0>(re[NR - 1], im[NR - 1], xbuf, xim, lane); X1::template read_half<1>(re[NR - 1], im[NR - 1], xbuf, xim, lane); wave_lds_sync(); }
@@ -273,12 +281,17 @@ __device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[
     }
     point(2);
     Tw<7> w3;
-    w3.load(tw + XTw::I3 + lane, 64);
+    w3.load(i3 + lane, 64);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         if (j == 0) { X2::template read_half<0>(re[NR - 1], im[NR - 1], xbuf, xim, lane); X2::template read_half<1>(re[NR - 1], im[NR - 1], xbuf, xim, lane); wave_lds_sync(); }
         inv_pass(re[j], im[j], w3.w);
     }
+}
+template <int NR, typename HOOK = NoPoint>
+__device__ __forceinline__ void inverse_multi(double (&re)[NR][R], double (&im)[NR][R], const cplx* __restrict__ tw,
+                                              double* __restrict__ xbuf, double* __restrict__ xim, int lane, HOOK point = HOOK()) {
+    inverse_core<NR>(re, im, tw + XTw::I2, tw + XTw::I3, xbuf, xim, lane, point);
     Tw<8> ut;
     ut.load(tw + XTw::UT + lane, 64);
 #pragma unroll

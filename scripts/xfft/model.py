@@ -140,6 +140,61 @@ def cross_exact(digits, key_rows):
     return np.array([int(x) & 0xFFFFFFFF for x in s], dtype=np.uint32)
 
 
+# ---- N = 2048 on the device: a 1024-point transform as TWO 512-point transforms, one per wave (rtfhe_kernels_xfft2.hpp) ------------------------
+# forward: stage 1 pairs z_j with z_{j+512} under ONE block twiddle c = exp(i pi/4); the "top" results (+) continue in the ring X^512 - c, the
+# "bottom" ones (-) in X^512 + c: two independent 512-point transforms of the N = 1024 shape with root angles pi/4 and pi/4 + pi -- wave h = 0 / 1
+# -- whose outputs are positions [512 h, 512 h + 512) of the full spectrum.  inverse: nine DIT stages inside each half, then the last stage across
+# the halves fused with the untwist:  y_q = T_q U_q + B_q V_q,  y_{q+512} = (T_q U_q - B_q V_q) e^{-i pi/4},  U_q = psi^-q / n,
+# V_q = omega^-q U_q  (psi = exp(i (pi/2) / n), omega = exp(2 pi i / n), n = 1024).
+def forward_halves(z):
+    """-> the full 1024-point spectrum computed as the device does (two halves)"""
+    c = np.exp(1j * np.pi / 4)
+    out = []
+    for h in (0, 1):
+        sub = Plan(1024, root_theta=np.pi / 4 + h * np.pi)
+        t = z[:512] + (c if h == 0 else -c) * z[512:]
+        out.append(sub.forward(t))
+    return np.concatenate(out)
+
+
+def inverse_halves(spec):
+    """-> 1024 complex values y_j (coefficient j = Re, coefficient j + 1024 = Im), untwisted and scaled, computed as the device does"""
+    n = 1024
+    sub = Plan(1024)                                   # only its inverse stage twiddles are used (the standard radix-2 DIT ones)
+    parts = []
+    for h in (0, 1):
+        z = np.array(spec[512 * h:512 * h + 512], dtype=np.complex128)
+        for t in range(1, 10):
+            half = 1 << (t - 1)
+            v = z.reshape(-1, 2, half)
+            tt = sub.iw[t - 1][None, :] * v[:, 1, :]
+            a = v[:, 0, :] + tt
+            z = np.stack([a, 2 * v[:, 0, :] - a], axis=1).reshape(-1)
+        parts.append(z)
+    T, B = parts
+    q = np.arange(512, dtype=np.longdouble)
+    ua = -(np.longdouble(np.pi) / 2 / n) * q
+    U = ((np.cos(ua) + 1j * np.sin(ua)) / n).astype(np.complex128)
+    va = ua - 2 * np.longdouble(np.pi) * q / n
+    V = ((np.cos(va) + 1j * np.sin(va)) / n).astype(np.complex128)
+    y_lo = T * U + B * V
+    D = T * U - B * V
+    s = np.sqrt(0.5)
+    y_hi = s * (D.real + D.imag) + 1j * s * (D.imag - D.real)
+    return np.concatenate([y_lo, y_hi])
+
+
+def check_halves(rng):
+    plan = Plan(2048)
+    z = rng.integers(-32, 32, 1024) + 1j * rng.integers(-32, 32, 1024)
+    full = plan.forward(z)
+    assert np.max(np.abs(forward_halves(z) - full)) < 1e-9 * np.max(np.abs(full)), "forward halves"
+    spec = full * plan.forward(rng.integers(-2 ** 15, 2 ** 15, 1024) + 1j * rng.integers(-2 ** 15, 2 ** 15, 1024))
+    ref = plan.inverse(spec)
+    got = inverse_halves(spec)
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref)), "inverse halves"
+
+
 def error_bound(N, rows=6, digit_max=32, half_max=2.0 ** 15):
     """Worst-case |computed - exact| of one rounded sum, every input (see the derivation in the module docstring of rtfhe_xfft.hpp):
     relative l2 error per butterfly stage <= 5u (two nested FMAs per component, b' = 2a - a', twiddle rounding), L stages per transform;
@@ -156,7 +211,19 @@ def error_bound(N, rows=6, digit_max=32, half_max=2.0 ** 15):
 
 def instruction_counts(N):
     """FP64-rate wave instructions per CMUX (two waves at N = 1024: each owns one polynomial's three digit rows) beside the mirror's 3,744 and the
-    NTT backend's 6,648."""
+    NTT backend's 6,648.  N = 2048: four waves (polynomial x half of the spectrum), beside the mirror's 8,112 and the NTT backend's 19,968."""
+    if N == 2048:
+        fwd = 3 * 12 * 6
+        inv9 = (4 * 4 + 4 * 4 + 2 * 4 + 2 * 6) + 2 * 12 * 6
+        per_wave = {
+            "int -> f64 of the digits and their stage-1 sums / differences (4 per point)": 3 * 8 * 4,
+            "stage 1 across the halves (one block twiddle: 2 FMA per point)": 3 * 8 * 2,
+            "forward transforms of the half (3)": 3 * fwd,
+            "multiply-accumulate (12 row-halves x 8 points x 4 FMA)": 12 * 8 * 4,
+            "nine inverse stages inside the half (hi, lo)": 2 * inv9,
+            "last inverse stage across the halves fused with untwist and rounding (20 per pair of outputs, 4 pairs)": 2 * 4 * 20,
+        }
+        return per_wave, 4 * sum(per_wave.values())
     assert N == 1024
     R = 8
     butterflies_per_pass = 12                   # three radix-2 stages on 8 points
@@ -210,11 +277,17 @@ def main():
         assert worst < bound and worst_wc < bound, (worst, worst_wc, bound)
         print("N = %4d: exact on random and worst-case inputs; distance from an integer before rounding: random %.3g (2^%.1f), worst-case patterns "
               "%.3g (2^%.1f); proven bound %.3g (2^%.1f) < 1/2" % (N, worst, np.log2(worst), worst_wc, np.log2(max(worst_wc, 1e-300)), bound, np.log2(bound)))
+    check_halves(rng)
+    print("N = 2048 as two 512-point halves per transform (forward: one block twiddle across the halves; inverse: last stage fused with the untwist): agrees with the whole transform")
     per_wave, per_cmux = instruction_counts(1024)
     for k, v in per_wave.items():
         print("  %-60s %5d per wave and step" % (k, v))
     print("FP64-rate instructions per CMUX (N = 1024): %d   (fft64 mirror 3,744; NTT backend 6,648)" % per_cmux)
     assert per_cmux < 5000
+    per_wave, per_cmux = instruction_counts(2048)
+    for k, v in per_wave.items():
+        print("  %-104s %5d per wave and step" % (k, v))
+    print("FP64-rate instructions per CMUX (N = 2048): %d   (fft64 mirror 8,112; NTT backend 19,968)" % per_cmux)
     return 0 if ok else 1
 
 

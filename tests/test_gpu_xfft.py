@@ -140,7 +140,7 @@ def test_xfft_fused_key_switch_gives_the_same_words(xe, keys, monkeypatch):
         e.close()
 
 
-def test_xfft_needs_torus_key_and_n1024(keys):
+def test_xfft_needs_torus_key(keys):
     import rustfhe_amd as R
     e = R.Engine(R.Params(), 0)
     try:
@@ -152,13 +152,117 @@ def test_xfft_needs_torus_key_and_n1024(keys):
         assert ei.value.code == R._ffi.ERR_STATE
     finally:
         e.close()
+
+
+# ---- N = 2048 (BASELINE config 5) on the split-FFT backend: k_bootstrap_xquad, four waves per gate (rtfhe_kernels_xfft2.hpp) ----
+@pytest.fixture(scope="module")
+def x2048(orc):
+    import rustfhe_amd as R
+    P = orc.Params(N=2048)
+    K = orc.Keys(P, 2048)
     e = R.Engine(R.Params(N=2048), 0)
+    e.load_bk_torus(K.bk_t)
+    e.load_ksk(K.ksk)
+    e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+    yield P, K, e
+    e.close()
+
+
+@pytest.mark.parametrize("steps", [0, 1, 2, 9])
+def test_xfft2048_blind_rotate_prefix_is_exact(x2048, orc, steps):
+    """One, two, nine CMUX steps of the four-wave kernel (one gate per workgroup: the latency shape of the dispatch) against the oracle's
+    schoolbook products: stage 1 across the halves, both hand-offs, the sibling trade of the last inverse stage, the update."""
+    P, K, e = x2048
+    c0, c1 = K.encrypt_bits([0, 1, 1]), K.encrypt_bits([1, 1, 0])
+    t = np.stack([orc.gate_linear(P, orc.NAND, a, b) for a, b in zip(c0, c1)])
+    acc = e.blind_rotate_batch(t, steps)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    exp = np.stack([orc.blind_rotate(P, pl, None, K.bk_t, x, steps) for x in t])
+    assert np.array_equal(acc.reshape(exp.shape), exp)
+
+
+def test_xfft2048_largest_sums_stay_exact(orc):
+    """Keys of extreme words against extreme digits at N = 2048: every half-product sum at 6 * 2048 * 32 * 2^15 = 2^34.6, all terms of an
+    output coefficient aligned; proven bound on the distance from an integer 2^-6.6 (scripts/xfft/model.py).  Through the bootstrap kernel's
+    own CMUX steps (the stage-level external product of this backend is N = 1024 only), in both launch shapes."""
+    import rustfhe_amd as R
+    P = orc.Params(n=6, N=2048)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    w = P.trgsw_words
+    words = [0x80000000, 0x7FFFFFFF, 0x7FFF8000, 0x80008000, 0x8000FFFF, 0x00008000]
+    bk = np.empty(len(words) * w, np.uint32)
+    for i, v in enumerate(words):
+        bk[i * w:(i + 1) * w] = v
+    bk[5 * w:6 * w:2] = 0x7FFF7FFF          # alternating signs in the last key
+    e = R.Engine(R.Params(n=6, N=2048), 0)
     try:
-        with pytest.raises(R.RtfheError) as ei:
-            e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
-        assert ei.value.code == R._ffi.ERR_INVALID
+        e.load_bk_torus(bk)
+        e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        t = np.zeros((3, P.n + 1), np.uint32)
+        t[1] = 0x12345678
+        t[2] = np.arange(P.n + 1, dtype=np.uint32) * 0x1F2E3D4C
+        for steps in (1, 6):
+            ex = np.stack([orc.blind_rotate(P, pl, None, bk, x, steps) for x in t])
+            acc = e.blind_rotate_batch(t, steps)
+            assert np.array_equal(acc.reshape(ex.shape), ex), steps
+            many = np.tile(t, (100, 1))                       # 300 gates: two gates per workgroup
+            accm = e.blind_rotate_batch(many, steps).reshape(100, 3, -1)
+            assert np.array_equal(accm, np.broadcast_to(ex, accm.shape)), steps
     finally:
         e.close()
+
+
+def test_xfft2048_equals_the_ntt_backend_in_every_launch_shape(x2048):
+    """Two independent exact backends must give the same words on every gate at N = 2048 too: 1,100 gates (> 2 gates per CU: workgroups
+    queue), then both launch shapes by batch size, the fused and the batch key switch, other gates, blind-rotate prefixes."""
+    import rustfhe_amd as R
+    P, K, e = x2048
+    rng = np.random.default_rng(2051)
+    G = 1100
+    b0, b1 = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
+    out = e.gate_batch(R.NAND, c0, c1)
+    assert K.decrypt_bits(out) == list(1 - (b0 & b1))
+    ntt = R.Engine(R.Params(N=2048), 0)
+    try:
+        ntt.load_bk_torus(K.bk_t)
+        ntt.load_ksk(K.ksk)
+        ntt.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        assert np.array_equal(out, ntt.gate_batch(R.NAND, c0, c1))
+        for op in (R.XOR, R.OR, R.NOT):
+            assert np.array_equal(e.gate_batch(op, c0[:70], c1[:70]), ntt.gate_batch(op, c0[:70], c1[:70])), op
+        assert np.array_equal(e.blind_rotate_batch(c0[:300], 5), ntt.blind_rotate_batch(c0[:300], 5))
+    finally:
+        ntt.close()
+    for k in (1, 5, 256, 257, 512, 513, 700, 1024):
+        assert np.array_equal(e.gate_batch(R.NAND, c0[:k], c1[:k]), out[:k]), k
+
+
+def test_xfft2048_fused_key_switch_gives_the_same_words(x2048, monkeypatch):
+    import rustfhe_amd as R
+    P, K, xe = x2048
+    monkeypatch.setenv("RTFHE_KS_MM_MIN", "0")
+    e = R.Engine(R.Params(N=2048), 0)
+    try:
+        e.load_bk_torus(K.bk_t)
+        e.load_ksk(K.ksk)
+        e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        rng = np.random.default_rng(2052)
+        b0, b1 = rng.integers(0, 2, 9), rng.integers(0, 2, 9)
+        c0, c1 = K.encrypt_bits(b0), K.encrypt_bits(b1)
+        assert np.array_equal(e.gate_batch(R.NAND, c0, c1), xe.gate_batch(R.NAND, c0, c1))
+        big = np.tile(c0, (40, 1)), np.tile(c1, (40, 1))      # 360 gates: two per workgroup, fused key switch with four waves summing quarters
+        assert np.array_equal(e.gate_batch(R.NAND, *big), np.tile(xe.gate_batch(R.NAND, c0, c1), (40, 1)))
+    finally:
+        e.close()
+
+
+def test_xfft2048_stage_level_external_product_is_refused(x2048):
+    import rustfhe_amd as R
+    P, K, e = x2048
+    with pytest.raises(R.RtfheError) as ei:
+        e.external_product_batch(np.zeros(1, np.int32), np.zeros((1, 2 * P.N), np.uint32))
+    assert ei.value.code == R._ffi.ERR_INVALID
 
 
 def test_xfft_runs_netlists(xe, params, keys):
