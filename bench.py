@@ -416,10 +416,16 @@ def xfft_dp_wave_instr_per_cmux(N=1024, l=3):
     rtfhe_kernels_xfft.hpp; the same count as scripts/xfft/model.py, checked against the built kernel's ISA by tests/test_bench_launcher.py).
     Every one of them but the conversions is a v_fma_f64 / v_fmac_f64 (or an addition of the first inverse pass): two flops each against the
     78.6 TFLOP/s FMA peak is the same fraction as one instruction each against the 39.3 T lane-instructions/s issue ceiling."""
-    assert N == 1024 and l == 3
+    assert N in (1024, 2048) and l == 3
     R = 8
     fwd = 3 * 12 * 6                                               # three passes of 12 radix-2 butterflies, 6 FMAs each; the twist is in the twiddles
     inv = (4 * 4 + 4 * 4 + 2 * 4 + 2 * 6) + 2 * 12 * 6             # first pass on twiddles 1, -i, (+-1 - i)/sqrt 2; two full passes
+    if N == 2048:
+        # four waves per gate (polynomial x half of the spectrum, rtfhe_kernels_xfft2.hpp): the digits and their stage-1 sums / differences
+        # converted (4 per point), stage 1 across the halves (2 FMAs per point), the half's 512-point transforms, the same twelve row
+        # multiply-accumulates, nine inverse stages, the last stage fused with untwist and rounding (20 per pair of outputs, 4 pairs, hi and lo)
+        per_wave = {"cvt": l * R * 4, "stage1": l * R * 2, "forward": l * fwd, "mac": 4 * l * R * 4, "inverse": 2 * inv, "last_stage_round": 2 * 4 * 20}
+        return {**per_wave, "per_wave": sum(per_wave.values()), "total": 4 * sum(per_wave.values())}
     per_wave = {"cvt": l * 2 * R, "forward": l * fwd, "mac": 4 * l * R * 4, "inverse": 2 * inv, "untwist_round": 2 * 2 * R * 2}
     return {**per_wave, "per_wave": sum(per_wave.values()), "total": 2 * sum(per_wave.values())}
 
@@ -637,6 +643,21 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
                 ok_s = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)[:gs]), (1 - (bb[0] & bb[1]))[:gs]))
                 small[str(gs)] = {"ms_per_launch": round(ms_s, 3), "gates_per_s": round(gs / ms_s * 1e3, 1), "ok": ok_s}
             sec["config5_n2048_small_batches"] = small
+            # the two exact backends at N = 2048: the NTT (two waves per transform) and the split FFT (k_bootstrap_xquad, four waves per gate),
+            # the latter compared word for word with the former
+            xn = torch.empty_like(x0)
+            e5.set_backend(R._ffi.BACKEND_NTT_EXACT)
+            ms_n, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xn, G, stream), 3)
+            e5.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+            ms_x, _ = timed(e5, lambda: e5.gate_batch_dev(R.NAND, x0, x1, xo, G, stream), 5)
+            ok_x = bool(np.array_equal(R.decrypt_bits(p5, k0, xo.cpu().numpy().view(np.uint32)), 1 - (bb[0] & bb[1])))
+            xops5 = xfft_dp_wave_instr_per_cmux(2048, p5.l)["total"]
+            sec["config5_n2048_exact_backends_1024_gates"] = {
+                "ntt_exact": {"gates_per_s": round(G / ms_n * 1e3, 1), "ms_per_launch": round(ms_n, 3), "kernel": "k_bootstrap_ntt_halves"},
+                "split_fft_exact": {"gates_per_s": round(G / ms_x * 1e3, 1), "ms_per_launch": round(ms_x, 3), "kernel": "k_bootstrap_xquad",
+                                    "dp_wave_instr_per_cmux": xops5, "roofline_frac_fp64_fma": fp64_frac(xops5, p5.n, G, ms_x * 1e-3),
+                                    "equals_ntt_exact_bit_for_bit": bool(torch.equal(xo, xn)), "ok": ok_x}}
+            e5.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
         finally:
             e5.close()
     guard("config5_n2048_1024_gates", _config5_n2048_1024_gates)

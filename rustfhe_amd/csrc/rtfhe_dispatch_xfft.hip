@@ -102,7 +102,6 @@ int launch_xpair_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     return 0;
 }
 
-// whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU (as the other two-waves-per-gate kernels)
 template <int GATES>
 int launch_xquad_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
     auto k = k_bootstrap_xquad<3, 6, 8, 2, KSQ, GATES>;
@@ -128,6 +127,7 @@ int launch_xquad(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return rem <= cus ? launch_xquad_g<1>(ctx, tail, s) : launch_xquad_g<2>(ctx, tail, s);
 }
 
+// whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU (as the other two-waves-per-gate kernels)
 int launch_xpair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_xpair);
     const size_t out_words = mode_out_words(a, 1024);

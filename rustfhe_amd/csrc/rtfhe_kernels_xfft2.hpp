@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_xquad(const XBoots
         else asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 2\n1:" ::"s"(side) : "scc");
     };
     if (side) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#ifdef RTFHE_WG_STAMPS
+    unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_loop0 = tprev, rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #define XQ_ARRIVE(k) xfft::flag_arrive(my_flag, 4u * (unsigned)i + (k))
 #define XQ_WAIT(flag, k) xfft::flag_wait(flag, 4u * (unsigned)i + (k))
 #pragma unroll 1
@@ -176,8 +180,10 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_xquad(const XBoots
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        PAIR_STAMP(0);
         prio(1);
         xfft::forward_multi_t<L>(xr, xi, twf + xfft::XTw::F2, twf + xfft::XTw::F3, w1, myx, myx + G::XSLOTS, ln, [&](int k) { prio(1 + k); });
+        PAIR_STAMP(1);
         prio(4);
 
         double sre[2][R], sim[2][R];       // [0]: hi sums, [1]: lo sums of the own output polynomial (this half of the spectrum); the partner's partials pass through [1]
@@ -195,14 +201,18 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_xquad(const XBoots
             const int phase = hr / 6, row = (hr % 6) / 2, hh = hr & 1;
             if (hr == 6) {
                 put(buf_mine + lane_now(), sre[1], sim[1]);
+                PAIR_STAMP(2);
                 XQ_ARRIVE(1u); XQ_WAIT(partner_flag, 1u);
+                PAIR_STAMP(3);
                 prio(5);
                 get(buf_peer + lane_now(), sre[0], sim[0]);
             }
             if (hr == 12) prio(6);
             if (hr == 18) {
                 put(buf_peer + lane_now(), sre[1], sim[1]);
+                PAIR_STAMP(4);
                 XQ_ARRIVE(2u); XQ_WAIT(partner_flag, 2u);
+                PAIR_STAMP(5);
                 prio(7);
                 get(buf_mine + lane_now(), sre[1], sim[1]);
             }
@@ -212,9 +222,11 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_xquad(const XBoots
             fetch(kb[hr % 3], hr + 3 < HALF_ROWS ? i : nxt, (hr + 3) % HALF_ROWS);
         }
 
+        PAIR_STAMP(6);
         prio(8);
         xfft::inverse_core<2>(sre, sim, tw + T2::I2, tw + T2::I3, myx, myx + G::XSLOTS, lane, [&](int k) { prio(8 + k); });
-        prio(11);
+        PAIR_STAMP(7);
+        prio(12);          // the trade and the last stage at side 0's high priority: 18.56 against 18.91 ms per 1,024 gates (profiles/r06/xquad_priorities.log)
         // the trade with the sibling: this wave keeps the points m in [4 h, 4 h + 4) of both sums and sends the other four
         {
             cplx* mine = buf_mine + lane_now();
@@ -226,7 +238,9 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_xquad(const XBoots
                     mine[(s * 4 + k) * 64] = make_double2(vr, vi);
                 }
         }
+        PAIR_STAMP(8);
         XQ_ARRIVE(3u); XQ_WAIT(sibling_flag, 3u);
+        PAIR_STAMP(9);
         {
             const int l2 = lane_now();
             const cplx* trade_theirs = buf_sib + l2;       // [2 sums][4][64] cplx
@@ -265,10 +279,22 @@ __global__ __launch_bounds__(256 * GATES, 1) void k_bootstrap_xquad(const XBoots
                     __hip_atomic_fetch_add(&poly[q + 512 * e], add[k][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
+        PAIR_STAMP(10);
         XQ_ARRIVE(4u); XQ_WAIT(sibling_flag, 4u);
-        prio(12);
+        PAIR_STAMP(11);
+        prio(13);
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef RTFHE_WG_STAMPS
+    if (a.dbg && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; k++) a.dbg[wave * 16 + k] = tsum[k];
+    if (a.dbg && blockIdx.x < 1024 && tid == 0) {
+        a.dbg[128 + 4 * blockIdx.x] = t_loop0;
+        a.dbg[128 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        a.dbg[128 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime() - rt_loop0;      // 100 MHz
+        a.dbg[128 + 4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    }
+#endif
     __syncthreads();
 
     if (a.mode == MODE_BLIND_ROTATE) {

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 os.environ["RTFHE_LIB"] = os.path.abspath(sys.argv[1])
 import rustfhe_amd as R
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-P = R.Params()
+P = R.Params(N=int(os.environ.get("RTFHE_N", "1024")))
 key0, key1, bk, ksk = R.keygen(P, 20211003)
 e = R.Engine(P, 0)
 e.load_bk_torus(bk); e.load_ksk(ksk)
@@ -33,14 +33,16 @@ e.L.rtfhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert e.L.rtfhe_debug_read_stamps(e.h, buf) == 0
 t = np.array(buf[:], dtype=np.float64).reshape(8, 16) / P.n
 names = ["gather+cvt", "forward x3", "M1+put", "sync1", "M2+M3+put", "sync2", "M4", "inverse x2", "update"]
+if P.N == 2048:       # k_bootstrap_xquad
+    names = ["gather+fold", "forward x3", "M1+put", "sync1", "M2+M3+put", "sync2", "M4", "inverse9 x2", "trade write", "sync3", "last stage+upd", "sync4"]
 print("cycles per step (s_memtime ticks = 100 MHz? see note) by wave; ok =", bool(np.array_equal(R.decrypt_bits(P, key0, out), 1 - (b0 & b1))))
 for k, nm in enumerate(names):
-    print("%-12s" % nm + " ".join("%8.0f" % t[w, k] for w in range(8)))
-print("%-12s" % "total" + " ".join("%8.0f" % t[w, :9].sum() for w in range(8)))
+    print("%-14s" % nm + " ".join("%8.0f" % t[w, k] for w in range(8)))
+print("%-12s" % "total" + " ".join("%8.0f" % t[w, :len(names)].sum() for w in range(8)))
 big = (C.c_ulonglong * 4096)()
 e.L.rtfhe_debug_read_wg_times.argtypes = [C.c_void_p, C.c_void_p]
 if e.L.rtfhe_debug_read_wg_times(e.h, big) == 0:
-    w = np.array(big[:], dtype=np.int64).reshape(1024, 4)[: (G + 3) // 4]
+    w = np.array(big[:], dtype=np.int64).reshape(1024, 4)[: min(1024, (G + (1 if P.N == 2048 else 3)) // (2 if P.N == 2048 else 4))]
     t0, t1 = w[:, 0], w[:, 1]
     dur = (t1 - t0) / P.n
     print("per-workgroup loop cycles per step: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f;  start spread %.0f ticks, end spread %.0f ticks, span(first start, last end) %.0f per step"

@@ -170,6 +170,9 @@ def test_xfft_opcount_formula_is_the_models():
     per_wave, per_cmux = model.instruction_counts(1024)
     o = bench.xfft_dp_wave_instr_per_cmux(1024, 3)
     assert o["total"] == per_cmux == 3072 and o["per_wave"] == sum(per_wave.values()) == 1536
+    per_wave2, per_cmux2 = model.instruction_counts(2048)
+    o2 = bench.xfft_dp_wave_instr_per_cmux(2048, 3)
+    assert o2["total"] == per_cmux2 == 6912 and o2["per_wave"] == sum(per_wave2.values()) == 1728
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
@@ -189,6 +192,16 @@ def test_xfft_opcount_matches_the_isa_of_the_built_kernel(device_asm):
     # products that open a partial sum (first row of phases M1 and M3: 8 points x 2 products x 2 phases)
     assert f64 - fma == o["cvt"] + 2 * 44 + 32, (f64, fma)
     assert "scratch_" not in body or len(re.findall(r"^\s*scratch_", body, re.M)) <= 8, "the step must not spill"
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_xfft_n2048_opcount_matches_the_isa_of_the_built_kernel(device_asm):
+    """k_bootstrap_xquad (N = 2048, four waves per gate): one wave's straight-line step holds the formula's 1,728 FP64-rate instructions."""
+    import bench
+    m = re.search(r"\n(_ZN5rtfhe17k_bootstrap_xquadILi3ELi6ELi8ELi2ELi3ELi2E\w+):[^\n]*\n(.*?)\n\.Lfunc_end", device_asm.read_text(), re.S)
+    assert m, "k_bootstrap_xquad not found in the device assembly"
+    f64 = len(re.findall(r"^\s*v_\w+_f64", m.group(2), re.M))
+    assert f64 == bench.xfft_dp_wave_instr_per_cmux(2048, 3)["per_wave"] == 1728, f64
 
 
 # ---- round 4: the headline must survive the death of a side leg (VERDICT r3 item 4) -------------------------------------------------
