@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 import rustfhe_amd as R
 
-DEFAULT_SHAPES = ((1024, ("fft", "ntt"), (1024, 768, 512, 300, 1280)), (2048, ("fft", "ntt"), (1024, 768, 512, 100)))
+DEFAULT_SHAPES = ((1024, ("fft", "ntt", "xfft"), (1024, 768, 512, 300, 1280)), (2048, ("fft", "ntt", "xfft"), (1024, 768, 512, 100)))
 
 
 def run(launches=200, shapes=DEFAULT_SHAPES, emit=print):
@@ -27,14 +27,14 @@ def run(launches=200, shapes=DEFAULT_SHAPES, emit=print):
         d0 = torch.from_numpy(R.encrypt_bits(P, key0, b0, 1).view(np.int32)).cuda()
         d1 = torch.from_numpy(R.encrypt_bits(P, key0, b1, 2).view(np.int32)).cuda()
         for be in backends:
-            e.set_backend(1 if be == "ntt" else 0)
+            e.set_backend({"fft": 0, "ntt": 1, "xfft": 2}[be])
             for G in counts:
                 ref = torch.empty_like(d0[:G]); out = torch.empty_like(d0[:G])
                 e.gate_batch_dev(R.NAND, d0, d1, ref, G, st)
                 torch.cuda.synchronize()
                 dec = R.decrypt_bits(P, key0, ref.cpu().numpy().view(np.uint32))
                 ok_dec = bool(np.array_equal(np.asarray(dec, np.uint8), 1 - (b0[:G] & b1[:G])))
-                n_launch = launches if be == "fft" else max(20, launches // 4)
+                n_launch = launches if be != "ntt" else max(20, launches // 4)
                 bad = 0
                 for _ in range(n_launch):
                     out.zero_()
