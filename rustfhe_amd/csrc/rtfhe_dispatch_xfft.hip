@@ -181,8 +181,14 @@ int launch_bootstrap_xfft(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { retu
 
 // external product of `count` TRLWE samples with bk[idx[g]] on this backend (stage-level entry point)
 int launch_extprod_xfft(rtfhe_ctx* ctx, const int32_t* d_idx, const uint32_t* d_in, uint32_t* d_out, int32_t count, hipStream_t s) {
-    if (ctx->logn != 10) return fail(ctx, RTFHE_ERR_INVALID, "the stage-level external product of the split-FFT exact backend is built for N = 1024 (at N = 2048 use "
-                                                             "rtfhe_blind_rotate_batch with a step count, or the NTT backend's stage call: the products are the same words)");
+    if (ctx->logn == 11) {      // one workgroup of two waves per sample
+        XExtProdArgs a{ctx->d_xtw, ctx->d_xbk, d_idx, d_in, d_out, count};
+        const size_t lds = (size_t)xfft::XTw2::TOTAL * sizeof(cplx) + (size_t)2 * 2 * Geo<10>::XSLOTS * sizeof(double) + (size_t)2 * 2 * 4 * 64 * sizeof(cplx);
+        if (int rc = allow_lds(ctx, k_external_product_xfft2<3, 6>, lds)) return rc;
+        hipLaunchKernelGGL((k_external_product_xfft2<3, 6>), dim3(count), dim3(128), lds, s, a);
+        HIPCHECK(ctx, hipGetLastError());
+        return 0;
+    }
     constexpr int W = 2;
     XExtProdArgs a{ctx->d_xtw, ctx->d_xbk, d_idx, d_in, d_out, count};
     const size_t lds = (size_t)XTw::TOTAL * sizeof(cplx) + (size_t)W * 2 * Geo<10>::XSLOTS * sizeof(double);

@@ -410,4 +410,107 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_xbk_build2(const XBkArgs a) {
     }
 }
 
+// ---- stage-level external product on this backend at N = 2048 (rtfhe_external_product_batch): one workgroup of TWO waves per sample, wave h owning
+// half h of every spectrum.  Off the timed path: every digit row is transformed on its own and all four sums (2 output polynomials x hi / lo) are
+// accumulated side by side; the last inverse stage is traded through LDS behind the workgroup's barrier.  The same device functions and the same
+// arithmetic as k_bootstrap_xquad: what a mismatch in a whole gate is localised with.
+template <int L, int BGBIT>
+__global__ __launch_bounds__(128, 1) void k_external_product_xfft2(const XExtProdArgs a) {
+    typedef Geo<10> G;
+    typedef xfft::XTw2 T2;
+    constexpr int N = 2048, P = 512, R = 8;
+    constexpr uint32_t M = decomp_mask(L, BGBIT);
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int idx = tid; idx < T2::TOTAL; idx += 128) tw[idx] = a.xtw[idx];
+    __syncthreads();
+    const cplx* twf = tw + T2::F + h * T2::FH;
+    cplx w1[7];
+#pragma unroll
+    for (int e = 0; e < 7; e++) w1[e] = twf[xfft::XTw::F1 + e];
+    const double c_s = h ? -xfft::SQRT_HALF : xfft::SQRT_HALF;
+    double* xbuf = reinterpret_cast<double*>(smem + (size_t)T2::TOTAL * sizeof(cplx)) + (size_t)h * 2 * G::XSLOTS;
+    cplx* trade = reinterpret_cast<cplx*>(smem + (size_t)T2::TOTAL * sizeof(cplx) + (size_t)2 * 2 * G::XSLOTS * sizeof(double));     // [2 waves][2 sums][4][64]
+    const int g = blockIdx.x;        // grid = count
+    const uint32_t* in = a.trlwe + (size_t)g * 2 * N;
+    const cplx* bk_i = a.xbk + (size_t)a.bk_index[g] * (4 * 12 * P);
+    double s[2][2][2][R];        // [comp][key half][re / im][R]: this half of the four spectra
+#pragma unroll
+    for (int comp = 0; comp < 2; comp++)
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int m = 0; m < R; m++) { s[comp][half][0][m] = 0.0; s[comp][half][1][m] = 0.0; }
+#pragma unroll 1
+    for (int side = 0; side < 2; side++) {
+#pragma unroll 1
+        for (int jj = 0; jj < L; jj++) {
+            double xr[1][R], xi[1][R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                int d[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) d[e] = decomp_digit((in[side * N + lane + 64 * m + P * e] + M) ^ M, BGBIT, jj);      // coefficients j, j + 512, j + 1024, j + 1536
+                xr[0][m] = __builtin_fma(c_s, (double)(d[1] - d[3]), (double)d[0]);
+                xi[0][m] = __builtin_fma(c_s, (double)(d[1] + d[3]), (double)d[2]);
+            }
+            xfft::forward_multi_t<1>(xr, xi, twf + xfft::XTw::F2, twf + xfft::XTw::F3, w1, xbuf, xbuf + G::XSLOTS, lane);
+#pragma unroll
+            for (int phase = 0; phase < 4; phase++) {
+                const int half = phase >> 1, comp = (phase & 1) ? side : 1 - side;
+                const cplx* row = bk_i + (size_t)(((side * 2 + h) * 12) + phase * L + jj) * P + lane;
+                cplx b[R];
+#pragma unroll
+                for (int m = 0; m < R; m++) b[m] = row[m * 64];
+                if (comp == 0) xfft::mac<false>(s[0][half][0], s[0][half][1], b, xr[0], xi[0]);
+                else xfft::mac<false>(s[1][half][0], s[1][half][1], b, xr[0], xi[0]);
+            }
+        }
+    }
+    uint32_t* o = a.out + (size_t)g * 2 * N;
+#pragma unroll 1
+    for (int comp = 0; comp < 2; comp++) {
+        double yr[2][R], yi[2][R];       // [0]: hi, [1]: lo
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int m = 0; m < R; m++) { yr[half][m] = comp ? s[1][half][0][m] : s[0][half][0][m]; yi[half][m] = comp ? s[1][half][1][m] : s[0][half][1][m]; }
+        xfft::inverse_core<2>(yr, yi, tw + T2::I2, tw + T2::I3, xbuf, xbuf + G::XSLOTS, lane);
+        __syncthreads();             // (the previous component's trade has been read by both waves)
+#pragma unroll
+        for (int sm = 0; sm < 2; sm++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                trade[((h * 2 + sm) * 4 + k) * 64 + lane] = make_double2(h ? yr[sm][k] : yr[sm][4 + k], h ? yi[sm][k] : yi[sm][4 + k]);
+        __syncthreads();
+        uint32_t add[4][4];
+#pragma unroll
+        for (int sm = 0; sm < 2; sm++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const cplx oth = trade[(((1 - h) * 2 + sm) * 4 + k) * 64 + lane];
+                const cplx uu = tw[T2::UV + ((h * 2 + 0) * 4 + k) * 64 + lane], vv = tw[T2::UV + ((h * 2 + 1) * 4 + k) * 64 + lane];
+                const double tr = h ? oth.x : yr[sm][k], ti = h ? oth.y : yi[sm][k];
+                const double br = h ? yr[sm][4 + k] : oth.x, bi = h ? yi[sm][4 + k] : oth.y;
+                const double y0r = __builtin_fma(tr, uu.x, __builtin_fma(-ti, uu.y, __builtin_fma(br, vv.x, __builtin_fma(-bi, vv.y, xfft::MAGIC))));
+                const double y0i = __builtin_fma(tr, uu.y, __builtin_fma(ti, uu.x, __builtin_fma(br, vv.y, __builtin_fma(bi, vv.x, xfft::MAGIC))));
+                const double dr = __builtin_fma(tr, uu.x, __builtin_fma(-ti, uu.y, __builtin_fma(-br, vv.x, bi * vv.y)));
+                const double di = __builtin_fma(tr, uu.y, __builtin_fma(ti, uu.x, __builtin_fma(-br, vv.y, -(bi * vv.x))));
+                const double y1r = __builtin_fma(xfft::SQRT_HALF, dr, __builtin_fma(xfft::SQRT_HALF, di, xfft::MAGIC));
+                const double y1i = __builtin_fma(xfft::SQRT_HALF, di, __builtin_fma(-xfft::SQRT_HALF, dr, xfft::MAGIC));
+                if (sm == 0) {
+                    add[k][0] = xfft::rounded_hi16(y0r); add[k][1] = xfft::rounded_hi16(y1r); add[k][2] = xfft::rounded_hi16(y0i); add[k][3] = xfft::rounded_hi16(y1i);
+                } else {
+                    add[k][0] += xfft::rounded_u32(y0r); add[k][1] += xfft::rounded_u32(y1r); add[k][2] += xfft::rounded_u32(y0i); add[k][3] += xfft::rounded_u32(y1i);
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[comp * N + lane + 64 * (4 * h + k) + P * e] = add[k][e];
+    }
+}
+
 }  // namespace rtfhe

@@ -45,7 +45,7 @@ def torus_distance(x_u32, y_u32):
     return d / 2.0 ** 32
 
 
-@pytest.mark.parametrize("N, n, backends", [(1024, 40, ("mirror", "ntt", "xfft")), (2048, 24, ("mirror", "ntt"))])
+@pytest.mark.parametrize("N, n, backends", [(1024, 40, ("mirror", "ntt", "xfft")), (2048, 24, ("mirror", "ntt", "xfft"))])
 def test_trgsw_cross_and_cmux_mean_what_the_reference_says(N, n, backends):
     import rustfhe_amd as R
     p = R.Params(N=N, n=n)

@@ -257,31 +257,48 @@ def test_xfft2048_fused_key_switch_gives_the_same_words(x2048, monkeypatch):
         e.close()
 
 
-def test_xfft2048_stage_level_external_product_is_refused(x2048):
-    import rustfhe_amd as R
+def test_xfft2048_external_product_is_exact(x2048, orc):
+    """The stage-level external product of this backend at N = 2048 (two waves per sample, the bootstrap kernel's own device functions): random
+    and extreme TRLWE samples against the oracle's schoolbook products."""
     P, K, e = x2048
-    with pytest.raises(R.RtfheError) as ei:
-        e.external_product_batch(np.zeros(1, np.int32), np.zeros((1, 2 * P.N), np.uint32))
-    assert ei.value.code == R._ffi.ERR_INVALID
+    rng = np.random.default_rng(2053)
+    idx = np.array([0, 5, 634, 300, 17, 99, 1], np.int32)
+    trlwe = rng.integers(0, 2 ** 32, (7, 2 * P.N), dtype=np.uint64).astype(np.uint32)
+    trlwe[1] = 0
+    trlwe[2] = 0xFFFFFFFF          # extreme digits / carries
+    trlwe[3] = 0x7DF7C000          # every digit at the top of its range
+    trlwe[4] = 0x82082000          # ... at the bottom
+    out = e.external_product_batch(idx, trlwe)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    w = P.trgsw_words
+    exp = np.stack([orc.external_product(P, pl, None, K.bk_t[i * w:(i + 1) * w], t) for i, t in zip(idx, trlwe)])
+    assert np.array_equal(out.reshape(exp.shape), exp)
 
 
-def test_xfft_runs_netlists(xe, params, keys):
-    """Circuit waves on this backend: one HIP-graph submission replays the same words as wave-by-wave launches, and the adder adds."""
-    from rustfhe_amd.circuit import CircuitRunner, ripple_carry_adder
-    net = ripple_carry_adder(4, nand_only=True)
-    for reps in (3, 200):
-        rng = np.random.default_rng(1900 + reps)
-        bits = rng.integers(0, 2, (reps, 8))
-        cts = keys.encrypt_bits(bits.reshape(-1)).reshape(reps, 8, params.n + 1)
-        g, w = CircuitRunner(xe, net, reps), CircuitRunner(xe, net, reps)
-        g.set_inputs(cts)
-        w.set_inputs(cts)
-        a = g.run(graph=True).outputs()
-        b = w.run(graph=False).outputs()
-        assert np.array_equal(a, b)
-        dec = np.array(keys.decrypt_bits(a.reshape(-1, params.n + 1))).reshape(reps, 5)
-        A = (bits[:, :4] * (1 << np.arange(4))).sum(axis=1)
-        B = (bits[:, 4:] * (1 << np.arange(4))).sum(axis=1)
-        assert np.array_equal((dec * (1 << np.arange(5))).sum(axis=1), A + B)
-        g.close()
-        w.close()
+def test_xfft2048_external_product_largest_sums(orc):
+    """... and on keys of extreme words against extreme digits: the sums at 2^34.6, every term of an output coefficient aligned."""
+    import rustfhe_amd as R
+    P = orc.Params(n=6, N=2048)
+    pl = orc.Plan(P.N, orc.BACKEND_EXACT)
+    w = P.trgsw_words
+    words = [0x80000000, 0x7FFFFFFF, 0x7FFF8000, 0x80008000, 0x8000FFFF, 0x00008000]
+    bk = np.empty(len(words) * w, np.uint32)
+    for i, v in enumerate(words):
+        bk[i * w:(i + 1) * w] = v
+    bk[5 * w:6 * w:2] = 0x7FFF7FFF
+    e = R.Engine(R.Params(n=6, N=2048), 0)
+    try:
+        e.load_bk_torus(bk)
+        e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        pats = np.empty((4, 2 * P.N), np.uint32)
+        pats[0] = 0x7DF7C000
+        pats[1] = 0x82082000
+        pats[2] = np.where(np.arange(2 * P.N) % 2 == 0, 0x7DF7C000, 0x82082000).astype(np.uint32)
+        pats[3] = np.where(np.arange(2 * P.N) % P.N < P.N // 2, 0x7DF7C000, 0x82082000).astype(np.uint32)
+        trlwe = np.concatenate([pats] * len(words))
+        idx = np.repeat(np.arange(len(words), dtype=np.int32), len(pats))
+        out = e.external_product_batch(idx, trlwe)
+        exp = np.stack([orc.external_product(P, pl, None, bk[i * w:(i + 1) * w], t) for i, t in zip(idx, trlwe)])
+        assert np.array_equal(out.reshape(exp.shape), exp)
+    finally:
+        e.close()
