@@ -13,7 +13,7 @@
 #   circuit          scripts/bench_circuit.py (the adder netlists)
 #   profile          rocprofv3 kernel trace + PMC passes of the headline on the driver's flags, --steps 20 --warmup 5 (scripts/profile_gpu.sh r06)
 #   profile2048      counters of the N = 2048 kernel (scripts/profile_n2048.sh eo)
-#   pmc:<kernel>:<gates>[:N[:matrix|plain[:fft|ntt]]]   counters of one kernel family on a batch (scripts/profile_kernel.sh)
+#   pmc:<kernel>:<gates>[:N[:matrix|cache|plain[:fft|ntt|xfft]]]   counters of one kernel family on a batch (scripts/profile_kernel.sh)
 #   ab:<N>:<gates>:<rounds>:<lib>[,<lib>...]   same-process A/B of builds under build/ab/ ("shipped" = rustfhe_amd/librtfhe_hip.so)
 #   ubench:<name>    scripts/ubench/<name> (a prebuilt micro-benchmark binary)
 #   clock:<name>     the shader clock scripts/ubench/<name>'s kernels ran at, launch by launch (scripts/kernel_clock.sh)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Board power and shader clock while a backend runs 1024-gate batches back to back for a few seconds (amdsmi / rocm-smi / hwmon, whichever the box offers).
-usage: power_probe.py <backend: fft|ntt|xfft> [seconds]      (RTFHE_LIB selects a variant build)"""
-import glob, json, os, subprocess, sys, threading, time
+"""Socket power of the GPU this process runs on while a backend bootstraps 1,024-gate batches back to back (rocm-smi --showpower, sampled from a
+thread twice a second under load; the box shows this container one card), beside the gates/s of the same seconds.
+usage: power_probe.py <backend: fft|ntt|xfft> [seconds] [N]      (RTFHE_LIB selects a variant build)"""
+import json, os, re, subprocess, sys, threading, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,8 +10,8 @@ import torch
 import rustfhe_amd as R
 
 backend = sys.argv[1] if len(sys.argv) > 1 else "fft"
-secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
-P = R.Params()
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
+P = R.Params(N=int(sys.argv[3]) if len(sys.argv) > 3 else 1024)
 key0, key1, bk, ksk = R.keygen(P, 20211003)
 e = R.Engine(P, 0)
 e.load_bk_torus(bk); e.load_ksk(ksk)
@@ -22,41 +23,47 @@ d0 = torch.from_numpy(R.encrypt_bits(P, key0, b0, 1).view(np.int32)).cuda(); d1 
 do = torch.empty_like(d0)
 st = torch.cuda.current_stream().cuda_stream
 
-def read_power():
-    out = {}
-    for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
-        try: out[f.split("/")[4] + ":" + os.path.basename(f)] = int(open(f).read()) / 1e6
-        except Exception: pass
-    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
-        try:
-            cur = [l for l in open(f).read().split("\n") if "*" in l]
-            if cur: out[f.split("/")[4] + ":sclk"] = cur[0].strip()
-        except Exception: pass
-    return out
 
+def smi():
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+        j = json.loads(out)
+        card = j[sorted(j)[0]]
+        watts = [float(v) for k, v in card.items() if "Power (W)" in k]
+        sclk = [int(re.sub(r"[^0-9]", "", v)) for k, v in card.items() if k.startswith("sclk clock speed")]
+        return (watts[0] if watts else None), (sclk[0] if sclk else None)
+    except Exception:       # noqa: BLE001
+        return None, None
+
+
+idle_w, idle_clk = smi()
 samples, stop = [], False
+
+
 def sampler():
     while not stop:
-        samples.append((time.time(), read_power()))
-        time.sleep(0.05)
-idle = read_power()
+        samples.append((time.time(),) + smi())
+        time.sleep(0.4)
+
+
+for _ in range(20):
+    e.gate_batch_dev(R.NAND, d0, d1, do, G, st)
+e.sync(st)
 th = threading.Thread(target=sampler); th.start()
 t0 = time.time(); n = 0
 e.timer_begin(st)
 while time.time() - t0 < secs:
-    for _ in range(20): e.gate_batch_dev(R.NAND, d0, d1, do, G, st)
+    for _ in range(20):
+        e.gate_batch_dev(R.NAND, d0, d1, do, G, st)
     e.sync(st); n += 20
 ms, _ = e.timer_end(st)
+t1 = time.time()
 stop = True; th.join()
-keys = sorted({k for _, s in samples for k in s if "power" in k})
-res = {"backend": backend, "lib": os.environ.get("RTFHE_LIB", "shipped"), "launches": n, "ms_per_launch": round(ms / n, 4), "gates_per_s": round(G * n / ms * 1e3, 1), "idle": idle}
-for k in keys:
-    v = [s[k] for _, s in samples[len(samples) // 4:] if k in s]
-    if v: res[k] = {"mean_W": round(float(np.mean(v)), 1), "max_W": round(float(np.max(v)), 1), "n": len(v)}
-sclk = [s[k] for _, s in samples[len(samples) // 4:] for k in s if k.endswith(":sclk")]
-res["sclk_seen"] = sorted(set(sclk))[:6]
-try:
-    res["rocm_smi"] = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout[:600]
-except Exception as ex:
-    res["rocm_smi"] = repr(ex)
-print(json.dumps(res))
+w = [s[1] for s in samples if s[1] is not None and t0 + 1.0 < s[0] < t1]
+c = [s[2] for s in samples if s[2] is not None and t0 + 1.0 < s[0] < t1]
+print(json.dumps({"backend": backend, "N": P.N, "lib": os.environ.get("RTFHE_LIB", "shipped"), "launches": n, "ms_per_launch": round(ms / n, 4),
+                  "gates_per_s": round(G * n / ms * 1e3, 1), "idle_W": idle_w, "idle_sclk_MHz": idle_clk,
+                  "socket_power_W_under_load": {"mean": round(float(np.mean(w)), 1), "min": min(w), "max": max(w), "samples": len(w)} if w else None,
+                  "sclk_MHz_reported_under_load": {"mean": round(float(np.mean(c)), 1), "min": min(c), "max": max(c)} if c else None,
+                  "note": "sclk is the driver's reported clock level, not the in-kernel clock (MI355X_MICROARCH.md: up to 10 % apart); the in-kernel clock is "
+                          "what the stamped builds measure (scripts/xfft_stamps.py)"}))

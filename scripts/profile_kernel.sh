@@ -6,6 +6,7 @@
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 KERN=$1; GATES=${2:-1024}; export RTFHE_N=${3:-1024} RTFHE_SKIP_STAGES=1
+[ -n "$RTFHE_LIB" ] && export RTFHE_LIB=$(realpath "$RTFHE_LIB")      # the passes run from /tmp: a relative path would not be found there
 OUT=$REPO/gpurun_out/pmc_kernel/${KERN}_N${RTFHE_N}_g$GATES
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
