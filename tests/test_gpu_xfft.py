@@ -118,6 +118,8 @@ def test_xfft_equals_the_ntt_backend_on_a_large_batch_in_every_launch_shape(xe, 
         for op in (R.XOR, R.OR, R.AND, R.NOT):
             assert np.array_equal(xe.gate_batch(op, c0[:70], c1[:70]), ntt.gate_batch(op, c0[:70], c1[:70])), op
         assert np.array_equal(xe.blind_rotate_batch(c0[:300], 7), ntt.blind_rotate_batch(c0[:300], 7))
+        assert np.array_equal(xe.mux_batch(c0[:9], c1[:9], c0[9:18]), ntt.mux_batch(c0[:9], c1[:9], c0[9:18]))      # three bootstraps, ANDNY among them
+        assert np.array_equal(xe.bootstrap_batch(c0[:5]), ntt.bootstrap_batch(c0[:5]))
     finally:
         ntt.close()
     for k in (1, 5, 256, 257, 512, 513, 768, 769, 1024, 1025, 1300):
@@ -232,6 +234,8 @@ def test_xfft2048_equals_the_ntt_backend_in_every_launch_shape(x2048):
         for op in (R.XOR, R.OR, R.NOT):
             assert np.array_equal(e.gate_batch(op, c0[:70], c1[:70]), ntt.gate_batch(op, c0[:70], c1[:70])), op
         assert np.array_equal(e.blind_rotate_batch(c0[:300], 5), ntt.blind_rotate_batch(c0[:300], 5))
+        assert np.array_equal(e.mux_batch(c0[:9], c1[:9], c0[9:18]), ntt.mux_batch(c0[:9], c1[:9], c0[9:18]))
+        assert K.decrypt_bits(e.mux_batch(c0[:9], c1[:9], c0[9:18])) == list(np.where(b0[:9], b0[9:18], b1[:9]))
     finally:
         ntt.close()
     for k in (1, 5, 256, 257, 512, 513, 700, 1024):
