@@ -306,3 +306,58 @@ def test_xfft2048_external_product_largest_sums(orc):
         assert np.array_equal(out.reshape(exp.shape), exp)
     finally:
         e.close()
+
+
+def test_xfft2048_runs_netlists_and_shards():
+    """N = 2048 on the split-FFT backend beyond plain batches: netlist waves through k_bootstrap_xquad's netlist mode (wire table, per-gate
+    opcodes; one HIP-graph submission replays the same words as wave-by-wave launches, and the adder adds) in both launch shapes, a batch
+    resident on the device sharded over a two-entry context, MUX on two streams.  Small TLWE dimension: key generation stays short."""
+    import torch
+    import rustfhe_amd as R
+    from rustfhe_amd.circuit import CircuitRunner, ripple_carry_adder
+    p = R.Params(N=2048, n=40)
+    key0, key1, bk, ksk = R.keygen(p, 20480)
+    e = R.Engine(p, 0)
+    m = R.Engine(p, devices=[0, 0])
+    try:
+        for eng in (e, m):
+            eng.load_bk_torus(bk); eng.load_ksk(ksk)
+            eng.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        net = ripple_carry_adder(4, nand_only=True)
+        for reps in (3, 150):                      # waves of 3..9 gates (one gate per workgroup) and 150..450 (two per workgroup)
+            rng = np.random.default_rng(2100 + reps)
+            bits = rng.integers(0, 2, (reps, 8)).astype(np.uint8)
+            cts = R.encrypt_bits(p, key0, bits.reshape(-1), 7).reshape(reps, 8, p.n + 1)
+            g, w = CircuitRunner(e, net, reps), CircuitRunner(e, net, reps)
+            g.set_inputs(cts); w.set_inputs(cts)
+            a = g.run(graph=True).outputs()
+            b = w.run(graph=False).outputs()
+            assert np.array_equal(a, b)
+            dec = np.array(R.decrypt_bits(p, key0, a.reshape(-1, p.n + 1))).reshape(reps, 5)
+            A = (bits[:, :4] * (1 << np.arange(4))).sum(axis=1)
+            B = (bits[:, 4:] * (1 << np.arange(4))).sum(axis=1)
+            assert np.array_equal((dec * (1 << np.arange(5))).sum(axis=1), A + B)
+            g.close(); w.close()
+        # sharded device-resident batch == single-device batch, word for word; ragged count
+        k = 777
+        rng = np.random.default_rng(2200)
+        b0, b1 = rng.integers(0, 2, k).astype(np.uint8), rng.integers(0, 2, k).astype(np.uint8)
+        d0 = torch.from_numpy(R.encrypt_bits(p, key0, b0, 1).view(np.int32)).cuda()
+        d1 = torch.from_numpy(R.encrypt_bits(p, key0, b1, 2).view(np.int32)).cuda()
+        o1, o2 = torch.empty_like(d0), torch.empty_like(d0)
+        st = torch.cuda.current_stream().cuda_stream
+        e.gate_batch_dev(R.XOR, d0, d1, o1, k, st); m.gate_batch_dev(R.XOR, d0, d1, o2, k, st); e.sync(st); m.sync(st)
+        assert torch.equal(o1, o2)
+        assert list(R.decrypt_bits(p, key0, o1.cpu().numpy().view(np.uint32))) == list(b0 ^ b1)
+        # MUX batches overlapping on two streams
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        ref = torch.empty_like(d0[:200]); e.mux_batch_dev(d0, d1, o1, ref, 200, st); e.sync(st)
+        x1, x2 = torch.zeros_like(ref), torch.zeros_like(ref)
+        for _ in range(2):
+            e.mux_batch_dev(d0, d1, o1, x1, 200, s1.cuda_stream)
+            e.mux_batch_dev(d0, d1, o1, x2, 200, s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(x1, ref) and torch.equal(x2, ref)
+    finally:
+        e.close(); m.close()
