@@ -600,6 +600,37 @@ __device__ __forceinline__ int32_t decomp_digit(uint32_t u, int bits, int j) {
     return __builtin_amdgcn_sbfe((int32_t)u, (uint32_t)(32 - bits * (j + 1)), (uint32_t)bits);
 }
 
+// Flags and counters in LDS, addressed by SCALAR registers.  The step holds 256 live vector registers at its peak and every vector register that
+// lives across it (an LDS address of a flag, say) costs a cascade of spills (measured: three such addresses, 2 -> 181 spilled registers); the
+// address therefore travels in an SGPR and is moved into a temporary inside the statement.  Each wait is ONE opaque statement (a loop the
+// compiler could see would become a block boundary in the middle of the step, with the same effect on the allocator); it sleeps between polls
+// so that the poll costs the SIMD's other wave next to nothing.
+
+// publishes k in the flag at LDS address `flag`
+__device__ __forceinline__ void flag_arrive(unsigned flag, unsigned k) {
+    unsigned t0, t1;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\tds_write_b32 %0, %1" : "=&v"(t0), "=&v"(t1) : "s"(flag), "s"(k) : "memory");
+}
+// waits until the flag / counter at LDS address `flag` has reached k
+__device__ __forceinline__ void flag_wait(unsigned flag, unsigned k) {
+    unsigned v, t;
+    asm volatile(
+        "v_mov_b32 %0, %2\n"
+        "1:\n\t"
+        "ds_read_b32 %0, %0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %1, %0\n\t"
+        "s_sub_i32 %1, %1, %3\n\t"
+        "s_cmp_lt_i32 %1, 0\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_sleep 1\n\t"
+        "v_mov_b32 %0, %2\n\t"
+        "s_branch 1b\n"
+        "2:"
+        : "=&v"(v), "=&s"(t)
+        : "s"(flag), "s"(k)
+        : "memory", "scc");
+}
 // negacyclic rotate read: coefficient c of X^r * p, p in LDS (utils/src/math.rs:85-132)
 template <int LOGN>
 __device__ __forceinline__ uint32_t rotated_coef(const uint32_t* __restrict__ p, int c, int r) {

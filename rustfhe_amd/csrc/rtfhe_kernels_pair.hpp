@@ -149,9 +149,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     constexpr int N = G::N, P = G::P, R = G::R, NT = 128 * GATES;
     constexpr uint32_t M = decomp_mask(L, BGBIT);
     static_assert(L == 3, "three rows per side are held in registers");
-    // the two waves of a gate synchronise through the workgroup barrier when the workgroup is full (4 gates: 6.74 vs 6.76 ms with pair_sync) and
-    // with each other only when it is not (2 / 3 gates per workgroup: 4.34 vs 4.37 ms at 512 gates, 6.14 vs 6.20 at 768)
-    constexpr bool FLAG_A = GATES < 4, FLAG_B = GATES < 4;
+    // The two waves of a gate meet through their own arrival flags in LDS at every workgroup size, never through the workgroup barrier (round 6).
+    // Round 3 had measured the barrier and a busy-polling pair_sync equal at four gates per workgroup (6.74 vs 6.76 ms); what the split-FFT
+    // kernel then showed (rtfhe_kernels_xfft.hpp: gates held in lock step collide on what a CU shares) holds here too once the wait costs the
+    // SIMD's other wave nothing -- flag addresses in scalar registers, a sleep between polls: 6.56 -> 6.41 ms per 1,024 gates, 52.06 -> 51.37
+    // per 8,192 (profiles/r06/pair_flags_ab.log).
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     // arrival counters of the pair (zeroed before the start-up barrier)
     uint32_t* flags = reinterpret_cast<uint32_t*>(gbase + PairLds::gate_bytes(a.npad) - PairLds::FLAGS);
     if (lane == 0) flags[side] = 0u;
-    [[maybe_unused]] const unsigned my_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side);
-    [[maybe_unused]] const unsigned partner_flag = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side));
+    const unsigned my_flag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + side));
+    const unsigned partner_flag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) uint32_t*)(flags + (1 - side)));
     double* xb1 = xb0 + 2 * G::XSLOTS;
     double* myx = side ? xb1 : xb0;
     cplx* hand0 = reinterpret_cast<cplx*>(xb0) + lane;    // [R][64] cplx
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         }
         prio_point(6);
         PAIR_STAMP(4);
-        if constexpr (FLAG_A) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 1u); else lds_barrier();
+        flag_arrive(my_flag, 2u * (unsigned)i + 1u); flag_wait(partner_flag, 2u * (unsigned)i + 1u);
         prio_point(7);
         PAIR_STAMP(5);
         // slot Q (both, same code): side 0 component 1 over rows 0..2 from +0.0 -> hand1; side 1 component 0 over rows 3..5
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         put(side ? hand0 : hand1);
         prio_point(8);
         PAIR_STAMP(6);
-        if constexpr (FLAG_B) pair_sync(my_flag, partner_flag, 2u * (unsigned)i + 2u); else lds_barrier();
+        flag_arrive(my_flag, 2u * (unsigned)i + 2u); flag_wait(partner_flag, 2u * (unsigned)i + 2u);
         prio_point(9);
         PAIR_STAMP(7);
         // slot R (side 1): component 1 over rows 3..5 on top of side 0's partial sum; side 0 picks up the finished s0

@@ -133,37 +133,9 @@ __device__ __forceinline__ uint32_t rounded_hi16(double v) {
     return (uint32_t)__double_as_longlong(v) & 0xFFFF0000u;
 }
 
-// Flags and counters in LDS, addressed by SCALAR registers.  The step holds 256 live vector registers at its peak and every vector register that
-// lives across it (an LDS address of a flag, say) costs a cascade of spills (measured: three such addresses, 2 -> 181 spilled registers); the
-// address therefore travels in an SGPR and is moved into a temporary inside the statement.  Each wait is ONE opaque statement (a loop the
-// compiler could see would become a block boundary in the middle of the step, with the same effect on the allocator); it sleeps between polls
-// so that the poll costs the SIMD's other wave next to nothing.
+using rtfhe::flag_arrive;      // (rtfhe_device.hpp: flags in LDS addressed by scalar registers, sleepy waits)
+using rtfhe::flag_wait;
 
-// publishes k in the flag at LDS address `flag`
-__device__ __forceinline__ void flag_arrive(unsigned flag, unsigned k) {
-    unsigned t0, t1;
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\tds_write_b32 %0, %1" : "=&v"(t0), "=&v"(t1) : "s"(flag), "s"(k) : "memory");
-}
-// waits until the flag / counter at LDS address `flag` has reached k
-__device__ __forceinline__ void flag_wait(unsigned flag, unsigned k) {
-    unsigned v, t;
-    asm volatile(
-        "v_mov_b32 %0, %2\n"
-        "1:\n\t"
-        "ds_read_b32 %0, %0\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 %1, %0\n\t"
-        "s_sub_i32 %1, %1, %3\n\t"
-        "s_cmp_lt_i32 %1, 0\n\t"
-        "s_cbranch_scc0 2f\n\t"
-        "s_sleep 1\n\t"
-        "v_mov_b32 %0, %2\n\t"
-        "s_branch 1b\n"
-        "2:"
-        : "=&v"(v), "=&s"(t)
-        : "s"(flag), "s"(k)
-        : "memory", "scc");
-}
 // s (+)= b * x, 4 FMA per point; FIRST: s = b * x
 template <bool FIRST>
 __device__ __forceinline__ void mac(double (&sre)[R], double (&sim)[R], const cplx (&b)[R], const double (&xr)[R], const double (&xi)[R]) {
