@@ -9,17 +9,18 @@
 //   side 0 (wave w, owns the b-poly)                       side 1 (wave w + GATES, owns the a-poly)
 //   gather/decompose b-poly, transforms of rows 0..2       gather/decompose a-poly, transforms of rows 3..5   (spectra in VGPRs)
 //   P: s0 = 0 + rows 0..2 of component 0    -> hand0
-//   --------------------------------------------- barrier 1 ----------------------------------------------------
+//   ------------------------------ hand-off 1 (the pair meets through its arrival flags in LDS) -----------------
 //   Q: s1 = 0 + rows 0..2 of component 1    -> hand1       Q: s0 = hand0 + rows 3..5 of component 0  -> hand0
-//   --------------------------------------------- barrier 2 ----------------------------------------------------
+//   ------------------------------ hand-off 2 --------------------------------------------------------------------
 //   s0 = hand0; inverse transform, += into the b-poly      R: s1 = hand1 + rows 3..5 of component 1; inverse, += into the a-poly
 //
 // * Fold order: every accumulator point sums rows 0, 1, ..., 5 from +0.0, exactly as the reference does
 //   (trgsw.rs:290-299): the partial sums travel between the waves, products are never re-associated -> bit-identical.
 // * Each side only ever reads and writes its OWN accumulator polynomial, so a side may run ahead into the next step's
-//   gather and transforms; the two barriers per step order the hand-offs only.  hand0 / hand1 are the (then idle)
-//   exchange buffers of side 0 / side 1: each is written only while its owner is between transforms, in program order
-//   with the barriers.
+//   gather and transforms; the two hand-offs per step order the partial sums only -- and only between the two waves of ONE gate (round 6:
+//   flag_arrive / flag_wait, rtfhe_device.hpp; rounds 1-5 used the workgroup barrier at four gates per workgroup, which held the four gates in
+//   lock step).  hand0 / hand1 are the (then idle) exchange buffers of side 0 / side 1: each is written only while its owner is between
+//   transforms, in program order with the hand-offs.
 // * Key rows go through a two-buffer register ring that runs ACROSS steps (each buffer is refilled right after its
 //   multiply-accumulate retires; the last refills of a step fetch rows of the next).  Slot Q is the same code for both
 //   sides, so the ring buffers are live in the same way on both paths at every control-flow merge -- the other
@@ -27,8 +28,8 @@
 //   register allocator spill 50-240 VGPRs, and scratch reloads share the vmcnt queue with the prefetches.
 // * Priority schedule (see prio_point): a SIMD does not share itself evenly between two busy waves (one runs at ~0.9 of
 //   its solo speed, the other on the leftovers; s_setprio selects which), so with fixed priorities one side races to each
-//   barrier and the SIMD then runs one wave; flipping side 0's priority twice per step makes both sides reach the
-//   barriers together (8.16 -> 7.70 ms per 1024 gates).
+//   hand-off and the SIMD then runs one wave; flipping side 0's priority twice per step makes both sides reach the
+//   hand-offs together (8.16 -> 7.70 ms per 1024 gates).
 // Measured (profiles/r01_pair): 7.70-7.75 ms per 1024 gates vs 8.69 ms for k_bootstrap's 4-wave shape, same outputs.
 #pragma once
 
@@ -45,7 +46,8 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Synchronisation of the TWO waves of one gate only (used at 2 / 3 gates per workgroup).  s_barrier is workgroup-wide although the four gates of a
+// Synchronisation of the TWO waves of one gate only, busy-polling form (k_bootstrap_pair's until round 6, still the four-wave and NTT kernels'
+// at small workgroups; k_bootstrap_pair now uses the sleepy scalar-addressed flag_arrive / flag_wait of rtfhe_device.hpp at every size).  s_barrier is workgroup-wide although the four gates of a
 // workgroup share nothing after start-up; the phase stamps show BOTH sides of a pair ~1.1 k cycles "at barrier 1", which looked like the pairs
 // waiting for the slowest gate.  Here each side publishes an arrival counter in LDS after its hand-off stores and polls its partner's (DS
 // instructions of a wave execute in order, so a partner that sees counter >= k also sees the stores issued before it; no fence, which would wait
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
     const cplx* twf = tw;
     const cplx* twi = tw + G::TW_DIR;
 
-    // idle pairs of the last workgroup shadow the last gate (they take part in every barrier) and store nothing
+    // idle pairs of the last workgroup shadow the last gate (they run every step and take part in the barriers of prologue and epilogue) and store nothing
     const int g_raw = blockIdx.x * GATES + slot;
     const int g = g_raw < a.count ? g_raw : a.count - 1;
     const GateIo io = gate_io(a, g);
-    const bool live = g_raw < a.count && io.ok;      // a skipped netlist gate still takes part in every barrier
+    const bool live = g_raw < a.count && io.ok;      // a skipped netlist gate still runs every step
 
     unsigned char* gbase = smem + PairLds::TW + (size_t)slot * PairLds::gate_bytes(a.npad);
     uint32_t* accbuf = reinterpret_cast<uint32_t*>(gbase);
@@ -252,12 +254,13 @@ __global__ __launch_bounds__(128 * GATES, 1) void k_bootstrap_pair(const Bootstr
         fetch(bB, 0, side ? 1 : 0);
     }
     // Priority schedule.  Of two waves that both have work a SIMD runs one at (nearly) full speed and the other on the
-    // leftovers (s_setprio selects which), so with fixed priorities the favoured side reaches every barrier early and the
+    // leftovers (s_setprio selects which), so with fixed priorities the favoured side reaches every hand-off early and the
     // SIMD then runs a single wave.  Side 1 stays at priority 1; side 0 runs at 2 from the end of a step (RAISE_AT) to the end of its pass 2
     // (LOWER_AT) and at 0 for the rest of the step -- its inverse then runs at low priority under side 1's slot R + inverse -- which splits the
-    // time between the barriers about evenly (profiles/r01_pair/priority_schedule_ab.log, profiles/r03/pair_priority_grid.log; the search over
+    // time between the hand-offs about evenly (profiles/r01_pair/priority_schedule_ab.log, profiles/r03/pair_priority_grid.log; the search over
     // every schedule these points allow: profiles/r04/pair_priority_search.log).  Points: 1 after pass 1, 2 after pass 2, 5 after pass 3,
-    // 6 before barrier 1, 7 after it, 8 before barrier 2, 9 after it, 10 end of step.
+    // 6 before hand-off 1, 7 after it, 8 before hand-off 2, 9 after it, 10 end of step (the window was searched again under the flag form in
+    // round 6 and is still the optimum: profiles/r06/pair_flags_ab.log).
     constexpr int LOWER_AT = 2, RAISE_AT = 10;
     auto prio_point = [&](int point) {   // one opaque statement each: no compiler-visible control flow inside the transforms
         if (point == LOWER_AT) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(side) : "scc");
