@@ -189,6 +189,7 @@ static int create_single(const rtfhe_params* p, int device_id, rtfhe_ctx** out) 
         if (const char* e = std::getenv("RTFHE_KS_MM_MIN")) ctx->ks_mm_min = std::atoi(e);
         if (const char* e = std::getenv("RTFHE_N2048_EO4")) ctx->eo4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("RTFHE_PAIR4")) ctx->pair4 = std::atoi(e);
+        if (const char* e = std::getenv("RTFHE_PAIR_RR")) ctx->rr = std::atoi(e);
     }
     if (!rc) rc = prime_fft_kernels(ctx);
     if (!rc) rc = prime_ntt_kernels(ctx);

@@ -4,6 +4,7 @@
 #include "rtfhe_kernels_wg.hpp"
 #include "rtfhe_kernels_pair.hpp"
 #include "rtfhe_kernels_pair4.hpp"
+#include "rtfhe_kernels_pair_rr.hpp"
 #include "rtfhe_kernels_eo.hpp"
 #include "rtfhe_kernels_eo4.hpp"
 
@@ -45,6 +46,24 @@ int launch_bootstrap_pair10_g(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return 0;
 }
 int launch_bootstrap_pair10(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) { return launch_bootstrap_pair10_g<4>(ctx, a, s); }
+// 4 x CUs < count <= rr x CUs gates on the four wave pairs of every CU, time-sliced (rtfhe_kernels_pair_rr.hpp)
+bool rr_applies(const rtfhe_ctx* ctx, size_t count) {
+    const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, rem = count % round;
+    const int rr = ctx->rr > PairRrLds::GMAX ? PairRrLds::GMAX : ctx->rr;
+    return rr > 4 && !ctx->force_waves && count > round && rem != 0 && round + rem <= (size_t)rr * cus;
+}
+int launch_bootstrap_pair_rr(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
+    auto k = k_bootstrap_pair_rr<3, 6, 8, 2, KSQ>;
+    const int wgs = ctx->num_cus, most = (a.count + wgs - 1) / wgs;
+    if (a.count < 4 * wgs || most > PairRrLds::GMAX)
+        return fail(ctx, RTFHE_ERR_STATE, "k_bootstrap_pair_rr: " + std::to_string(a.count) + " gates on " + std::to_string(wgs) + " CUs is not a shape it serves");
+    const size_t lds = PairRrLds::bytes(most, a.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(512), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
 // four waves per gate, (polynomial, parity): up to two gates per CU (rtfhe_kernels_pair4.hpp); no fused key switch
 template <int GATES>
 int launch_bootstrap_pair4_g(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
@@ -115,6 +134,13 @@ int launch_bootstrap_t(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
         // four waves per gate (k_bootstrap_pair4) where k_bootstrap_pair would leave SIMDs a lone wave: tails of more than wg_max gates and up to
         // two / three gates per CU (7 % on 257-512-gate and 1-4 % on 513-768-gate batches; at four gates per CU it loses 12 %, profiles/r04/pair4_ab.log)
         const bool p4 = ctx->p4bk_valid && (a.mode == MODE_EXTRACT || a.mode == MODE_BLIND_ROTATE);
+        if (rr_applies(ctx, count)) {
+            // the last whole round and the remainder as ONE launch of five or six gates per CU: (4 + rem / CUs) / 4 rounds instead of 2
+            // (1,280 gates 9.3 -> 8.2 ms; profiles/r06/pair_rr_sweep.log)
+            if (full > round)
+                if (int rc = launch_bootstrap_pair10(ctx, batch_segment(ctx, a, 0, full - round, out_words), s)) return rc;
+            return launch_bootstrap_pair_rr(ctx, batch_segment(ctx, a, full - round, round + rem, out_words), s);
+        }
         if (full)
             if (int rc = launch_bootstrap_pair10(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
         if (rem) {
@@ -153,6 +179,7 @@ int layout_needed(const rtfhe_ctx* ctx, size_t count, int mode) {
     if (ctx->logn == 11) return ctx->force_waves == 4 ? LAYOUT_NONE : LAYOUT_EO;
     if (ctx->force_waves || ctx->pair4 < 2) return LAYOUT_NONE;
     const size_t cus = (size_t)ctx->num_cus, rem = count % (4 * cus);
+    if (rr_applies(ctx, count)) return LAYOUT_NONE;      // the remainder rides with the last whole round (k_bootstrap_pair_rr reads d_bk)
     // (a MODE_GATE batch reaches the four-wave kernel through the split path only, as MODE_EXTRACT: without the matrix form of the key it stays on the fused kernels)
     if (mode == MODE_GATE && !(ctx->d_ksmat && ctx->ks_mm_min > 0 && count >= (size_t)ctx->ks_mm_min)) return LAYOUT_NONE;
     return (rem > (size_t)ctx->wg_max && rem <= (size_t)(ctx->pair4 < 3 ? 2 : 3) * cus) ? LAYOUT_P4 : LAYOUT_NONE;
@@ -292,6 +319,15 @@ int prime_fft_kernels(rtfhe_ctx* ctx) {
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 3>, PairLds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_pair<3, 6, 8, 2, KSQ, 2>, PairLds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_wg<10, 3, 6, 8, 2, KSQ>, WgLds<10, 3>::bytes(npad))) return rc;
+        // the time-sliced launch: as many gates per CU (five or six) as this mask length leaves room for in 160 KiB of LDS
+        {
+            int fit = 0;
+            for (int g = 5; g <= PairRrLds::GMAX; g++)
+                if (PairRrLds::bytes(g, npad) <= (size_t)160 * 1024) fit = g;
+            if (ctx->rr > fit) ctx->rr = fit;
+            if (ctx->rr >= 5)
+                if (int rc = allow_lds(ctx, k_bootstrap_pair_rr<3, 6, 8, 2, KSQ>, PairRrLds::bytes(ctx->rr, npad))) return rc;
+        }
         if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 3>, Pair4Lds::bytes(3, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap_pair4<3, 6, 2>, Pair4Lds::bytes(2, npad))) return rc;
         if (int rc = allow_lds(ctx, k_bootstrap<10, 3, 6, 8, 2, KSQ, 4>, bootstrap_lds_bytes<10>(4, npad, bootstrap_dual_xbuf(10, 4)))) return rc;

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 import rustfhe_amd as R
 
-DEFAULT_SHAPES = ((1024, ("fft", "ntt", "xfft"), (1024, 768, 512, 300, 1280)), (2048, ("fft", "ntt", "xfft"), (1024, 768, 512, 100)))
+DEFAULT_SHAPES = ((1024, ("fft", "ntt", "xfft"), (1024, 768, 512, 300, 1280, 1500)), (2048, ("fft", "ntt", "xfft"), (1024, 768, 512, 100)))
 
 
 def run(launches=200, shapes=DEFAULT_SHAPES, emit=print):

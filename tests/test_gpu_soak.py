@@ -15,9 +15,10 @@ def test_repeated_launches_of_every_flag_synchronised_shape_give_the_same_words(
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import soak
     lines = []
-    # N = 1024: 4 gates per workgroup (workgroup barrier), 3 and 2 (pair_sync), a ragged batch; N = 2048: the ping-pong trade at 4 / 3 gates
+    # N = 1024: 4 gates per workgroup, 3 and 2, a ragged batch, five and six gates per CU time-sliced (k_bootstrap_pair_rr: a gate changes hands
+    # between wave pairs through LDS flags); N = 2048: the ping-pong trade at 4 / 3 gates
     # per workgroup, the duplicated first stage at 2; the NTT backend's pair-synchronised shapes at a quarter of the launches
-    shapes = ((1024, ("fft", "ntt"), (1024, 768, 512, 300)), (2048, ("fft", "ntt"), (1024, 768, 512)))
+    shapes = ((1024, ("fft", "ntt"), (1024, 768, 512, 300, 1280, 1500)), (2048, ("fft", "ntt"), (1024, 768, 512)))
     bad = soak.run(60, shapes, emit=lines.append)
     assert bad == 0, "\n".join(lines)
-    assert len(lines) == 14
+    assert len(lines) == 18
