@@ -119,6 +119,23 @@ def test_dp_opcount_matches_the_isa_of_the_built_kernel(device_asm):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_time_sliced_kernel_executes_the_pair_kernels_operation_list(device_asm):
+    """k_bootstrap_pair_rr (five or six gates time-sliced over a CU's four wave pairs) claims k_bootstrap_pair's arithmetic per CMUX: the same
+    static count of FP64 instructions in its code, none of them fused."""
+    import bench
+    text = device_asm.read_text()
+    counts = {}
+    for name in ("16k_bootstrap_pair", "19k_bootstrap_pair_rr"):
+        m = re.search(r"\n(_ZN5rtfhe%s\w+):[^\n]*\n(.*?)\n\.Lfunc_end" % name, text, re.S)
+        assert m, name
+        body = m.group(2)
+        assert not re.findall(r"^\s*v_fma_f64", body, re.M), name
+        counts[name] = (len(re.findall(r"^\s*v_(?:add|mul)_f64", body, re.M)), len(re.findall(r"^\s*v_(?:cvt_f64_i32|trunc_f64)", body, re.M)))
+    assert counts["19k_bootstrap_pair_rr"] == counts["16k_bootstrap_pair"], counts
+    assert counts["16k_bootstrap_pair"][1] == bench.dp_wave_instr_per_cmux(1024, 3)["cvt_trunc"] // 2
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
 def test_n2048_parity_split_kernel_executes_the_reference_operation_list(device_asm):
     """k_bootstrap_eo holds its step loop twice (one copy per parity, each with its polynomial loop and its component loop not unrolled): the
     FP64-rate instructions of the two copies together are what the two waves of a gate execute per (polynomial + component) -- the reference's
