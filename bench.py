@@ -601,7 +601,8 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
                                         "equals_ntt_exact_bit_for_bit": same, "ok": okx}
     guard("xfft_exact_1024_gates", _xfft_exact_1024_gates)
     # -- tail behaviour on the driver's clock: batches that do not fill whole rounds of 4 gates per CU (default dispatch: a remainder of
-    #    <= 1 gate per CU on the latency shape, <= 2 / <= 3 per CU on 2 / 3 gates per workgroup); two untimed launches, then three timed
+    #    <= 1 gate per CU on the latency shape, <= 2 / <= 3 per CU on 2 / 3 gates per workgroup; 1,280 and 1,536 gates: one time-sliced launch of
+    #    five / six gates per CU, k_bootstrap_pair_rr); two untimed launches, then three timed
     def _batch_sweep():
         sizes = (256, 512, 768, 1280, 1536)
         Gm = max(sizes)
