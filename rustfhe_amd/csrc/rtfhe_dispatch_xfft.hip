@@ -6,6 +6,7 @@
 
 #include "rtfhe_kernels_xfft.hpp"
 #include "rtfhe_kernels_xfft2.hpp"
+#include "rtfhe_kernels_xfft_rr.hpp"
 
 using namespace rtfhe;
 using namespace rtfhe_host;
@@ -127,12 +128,35 @@ int launch_xquad(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     return rem <= cus ? launch_xquad_g<1>(ctx, tail, s) : launch_xquad_g<2>(ctx, tail, s);
 }
 
-// whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU (as the other two-waves-per-gate kernels)
+// 4 x CUs < count <= 6 x CUs gates on the four wave pairs of every CU, time-sliced (rtfhe_kernels_xfft_rr.hpp; the mirror backend's
+// k_bootstrap_pair_rr on this backend's arithmetic)
+int launch_xpair_rr(rtfhe_ctx* ctx, BootstrapArgs b, hipStream_t s) {
+    auto k = k_bootstrap_xpair_rr<3, 6, 8, 2, KSQ>;
+    const int wgs = ctx->num_cus, most = (b.count + wgs - 1) / wgs;
+    if (b.count < 4 * wgs || most > XPairRrLds::GMAX)
+        return fail(ctx, RTFHE_ERR_STATE, "k_bootstrap_xpair_rr: " + std::to_string(b.count) + " gates on " + std::to_string(wgs) + " CUs is not a shape it serves");
+    const size_t lds = XPairRrLds::bytes(most, b.npad);
+    if (int rc = allow_lds(ctx, k, lds)) return rc;
+    XBootstrapArgs a{b, ctx->d_xtw, ctx->d_xbk};
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(512), lds, s, a);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+
+// whole rounds of 4 gates per CU in one launch; a remainder with 1 / 2 / 3 gates per workgroup, one workgroup per CU (as the other two-waves-per-gate
+// kernels); behind at least one whole round, a remainder of up to 2 gates per CU rides with the last whole round in one time-sliced launch
 int launch_xpair(rtfhe_ctx* ctx, BootstrapArgs a, hipStream_t s) {
     if (split_ok(ctx, a, s)) return launch_split(ctx, a, s, launch_xpair);
     const size_t out_words = mode_out_words(a, 1024);
     const size_t cus = (size_t)ctx->num_cus, round = 4 * cus, count = (size_t)a.count;
     const size_t full = count / round * round, rem = count - full;
+    const int rr = ctx->xrr > XPairRrLds::GMAX ? XPairRrLds::GMAX : ctx->xrr;
+    if (rr > 4 && full && rem && round + rem <= (size_t)rr * cus) {
+        if (full > round)
+            if (int rc = launch_xpair_g<4>(ctx, batch_segment(ctx, a, 0, full - round, out_words), s)) return rc;
+        return launch_xpair_rr(ctx, batch_segment(ctx, a, full - round, round + rem, out_words), s);
+    }
     if (full)
         if (int rc = launch_xpair_g<4>(ctx, batch_segment(ctx, a, 0, full, out_words), s)) return rc;
     if (!rem) return 0;
@@ -206,6 +230,14 @@ int prime_xfft_kernels(rtfhe_ctx* ctx) {
         return 0;
     }
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 4>, XPairLds::bytes(4, npad))) return rc;
+    {   // the time-sliced launch: five or six gates per CU, as many as this mask length leaves room for in 160 KiB of LDS
+        int fit = 0;
+        for (int g = 5; g <= XPairRrLds::GMAX; g++)
+            if (XPairRrLds::bytes(g, npad) <= (size_t)160 * 1024) fit = g;
+        ctx->xrr = ctx->rr < fit ? ctx->rr : fit;
+        if (ctx->xrr >= 5)
+            if (int rc = allow_lds(ctx, k_bootstrap_xpair_rr<3, 6, 8, 2, KSQ>, XPairRrLds::bytes(ctx->xrr, npad))) return rc;
+    }
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 3>, XPairLds::bytes(3, npad))) return rc;
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 2>, XPairLds::bytes(2, npad))) return rc;
     if (int rc = allow_lds(ctx, k_bootstrap_xpair<3, 6, 8, 2, KSQ, 1>, XPairLds::bytes(1, npad))) return rc;

@@ -64,6 +64,7 @@ struct rtfhe_ctx {
                                       // `pair4` gates per CU (RTFHE_PAIR4: 0 = never, 2, 3 = default)
     int rr = 6;                       // N = 1024: a last whole round and the remainder behind it, up to `rr` gates per CU in all, as ONE time-sliced launch
                                       // (k_bootstrap_pair_rr; RTFHE_PAIR_RR: 0 = never, 5, 6 = default)
+    int xrr = 0;                      // ... the same on the split-FFT exact backend (k_bootstrap_xpair_rr): min(rr, what fits), set when that backend's kernels are primed
     int eo4 = 1;                      // N = 2048, up to two gates per CU: 1 = four waves per gate (k_bootstrap_eo4), 0 = two (RTFHE_N2048_EO4)
     int backend = RTFHE_BACKEND_FFT64_MIRROR;
     uint32_t* d_bk_torus = nullptr;   // kept when the key came in torus form: source for the NTT-domain key

@@ -209,6 +209,11 @@ def test_xfft_opcount_matches_the_isa_of_the_built_kernel(device_asm):
     # products that open a partial sum (first row of phases M1 and M3: 8 points x 2 products x 2 phases)
     assert f64 - fma == o["cvt"] + 2 * 44 + 32, (f64, fma)
     assert "scratch_" not in body or len(re.findall(r"^\s*scratch_", body, re.M)) <= 8, "the step must not spill"
+    # the time-sliced launch of the same backend (five or six gates on a CU's four wave pairs) holds the same step
+    mr = re.search(r"\n(_ZN5rtfhe20k_bootstrap_xpair_rr\w+):[^\n]*\n(.*?)\n\.Lfunc_end", device_asm.read_text(), re.S)
+    assert mr, "k_bootstrap_xpair_rr not found in the device assembly"
+    assert len(re.findall(r"^\s*v_\w+_f64", mr.group(2), re.M)) == f64 and len(re.findall(r"^\s*v_fma(?:c)?_f64", mr.group(2), re.M)) == fma
+    assert not re.findall(r"^\s*scratch_", mr.group(2), re.M)
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")

@@ -95,3 +95,39 @@ def test_time_sliced_launch_in_a_netlist_wave(engine, keys):
     exp = np.select([ops == R.NAND, ops == R.AND, ops == R.OR, ops == R.XOR], [1 - (x & y), x & y, x | y, x ^ y])
     keep = np.arange(cnt) != bad
     assert list(np.asarray(keys.decrypt_bits(out[keep]))) == list(exp[keep])
+
+
+def test_time_sliced_launch_on_the_split_fft_exact_backend(orc, params, keys, monkeypatch):
+    """The same launch shape on the split-FFT exact backend (k_bootstrap_xpair_rr): the words of whole rounds + tail, of the NTT backend (exact
+    products have one value), in the split and the fused key-switch form and for blind-rotation prefixes."""
+    import rustfhe_amd as R
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = np.random.default_rng(77)
+    G = 2 * 4 * cus + 2 * cus
+    c0 = rng.integers(0, 2 ** 32, (G, params.n + 1), dtype=np.uint64).astype(np.uint32)
+    c1 = rng.integers(0, 2 ** 32, (G, params.n + 1), dtype=np.uint64).astype(np.uint32)
+    sliced = _engine(R, params, monkeypatch, {})
+    whole = _engine(R, params, monkeypatch, {"RTFHE_PAIR_RR": "0"})
+    fused = _engine(R, params, monkeypatch, {"RTFHE_KS_MM_MIN": "0"})
+    try:
+        for e in (sliced, whole, fused):
+            e.load_bk_torus(keys.bk_t)
+            e.load_ksk(keys.ksk)
+            e.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+        ref = whole.gate_batch(R.NAND, c0, c1)
+        for k in (4 * cus + 1, 5 * cus - 1, 5 * cus, 5 * cus + 40, 6 * cus, 6 * cus + 1, 8 * cus + 9, G):
+            assert np.array_equal(sliced.gate_batch(R.NAND, c0[:k], c1[:k]), ref[:k]), k
+        for k in (4 * cus + 3, 6 * cus - 1):
+            assert np.array_equal(fused.gate_batch(R.NAND, c0[:k], c1[:k]), ref[:k]), k
+        k = 5 * cus + 17
+        t = np.stack([orc.gate_linear(params, orc.NAND, x, y) for x, y in zip(c0[:k], c1[:k])])
+        for steps in (1, 3):
+            assert np.array_equal(sliced.blind_rotate_batch(t, steps), whole.blind_rotate_batch(t, steps)), steps
+        whole.set_backend(R._ffi.BACKEND_NTT_EXACT)
+        k = 5 * cus + 40
+        assert np.array_equal(sliced.gate_batch(R.XOR, c0[:k], c1[:k]), whole.gate_batch(R.XOR, c0[:k], c1[:k]))
+        b0, b1 = rng.integers(0, 2, 6 * cus - 5), rng.integers(0, 2, 6 * cus - 5)
+        assert keys.decrypt_bits(sliced.gate_batch(R.AND, keys.encrypt_bits(b0), keys.encrypt_bits(b1))) == list(b0 & b1)
+    finally:
+        sliced.close(); whole.close(); fused.close()
