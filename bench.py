@@ -616,6 +616,19 @@ def secondary_measurements(R, params, eng, key0, bk, ksk, gpu, stream, torch, np
             oks = bool(np.array_equal(R.decrypt_bits(params, key0, so[:Gs].cpu().numpy().view(np.uint32)), 1 - (bb[0][:Gs] & bb[1][:Gs])))
             sweep[str(Gs)] = {"gates_per_s": round(Gs / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "key_switch_ms": round(ks, 3), "ok": oks}
         sec["batch_sweep"] = sweep
+        # the same two sizes between rounds on the split-FFT exact backend (k_bootstrap_xpair_rr), words compared with the NTT backend's
+        xs = {}
+        for Gs in (1280, 1536):
+            sn = torch.empty_like(so)
+            eng.set_backend(R._ffi.BACKEND_NTT_EXACT)
+            eng.gate_batch_dev(R.NAND, s0, s1, sn, Gs, stream); eng.sync(stream)
+            eng.set_backend(R._ffi.BACKEND_FFT_SPLIT_EXACT)
+            try:
+                ms, ks = timed(eng, lambda: eng.gate_batch_dev(R.NAND, s0, s1, so, Gs, stream), 3)
+                xs[str(Gs)] = {"gates_per_s": round(Gs / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "equals_ntt_exact_bit_for_bit": bool(torch.equal(so[:Gs], sn[:Gs]))}
+            finally:
+                eng.set_backend(R._ffi.BACKEND_FFT64_MIRROR)
+        sec["batch_sweep_split_fft_exact"] = xs
     guard("batch_sweep", _batch_sweep)
     # -- BASELINE configs[4]: N = 2048, 1024 gates (its own key set and context)
     def _config5_n2048_1024_gates():
